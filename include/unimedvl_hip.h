@@ -1,0 +1,155 @@
+/*
+ * libunimedvl_hip.so - C ABI of the MI355X (gfx950) kernel library that replaces the
+ * third-party native ops on UniMedVL's forward path (SURVEY.md section 2.2 / 8b "B2").
+ *
+ * The reference has no FFI of its own: its native work is reached through
+ * flash_attn / torch.nn.functional calls from Python.  Each entry point below names
+ * the reference call site(s) it stands in for (paths relative to
+ * /root/reference/codes/).  All pointers are DEVICE pointers owned by the caller;
+ * nothing here allocates persistent memory; every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*).  Return 0 on success, negative on error
+ * (message from umv_last_error()); nothing throws across the ABI.
+ *
+ * bf16 tensors are uint16_t bit patterns.  "rows" are tokens (packed NaViT
+ * sequences have no batch dimension, as in the reference).
+ */
+#ifndef UNIMEDVL_HIP_H
+#define UNIMEDVL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* umv_stream_t;
+
+int umv_version(void);
+const char* umv_last_error(void);
+
+/* ------------------------------------------------------------------ weights
+ * nn.Linear weights [N,K] (row-major, modeling_qwen2.py:283-286, 229-231) are
+ * re-tiled ONCE at load time into MFMA A-fragment order:
+ *   P[n/16][k/32][lane = ((k%32)/8)*16 + n%16][k%8], zero padded to N%16==0, K%32==0
+ * so that a wavefront streams 1 KiB contiguous per 16x32 tile. */
+size_t umv_packed_weight_elems(int N, int K);
+int umv_pack_weight_bf16(const uint16_t* w, uint16_t* packed, int N, int K, umv_stream_t stream);
+/* gate_proj / up_proj [I,K] each -> one packed [2I,K] with 16-row tiles interleaved
+ * (gate tile t, up tile t, ...) so SwiGLU fuses into the GEMM epilogue. */
+int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int I, int K,
+                                umv_stream_t stream);
+
+/* ------------------------------------------------------------------ GEMM
+ * out[m,n] = epilogue(sum_k x[m,k] * W[n,k]); fp32 accumulate on MFMA; replaces
+ * F.linear at qwen2_navit.py:541-543,555-562,617-620, modeling_qwen2.py:234-235,
+ * bagel.py:1295,1104,1133, siglip_navit.py:190,216-218,243,256-258,
+ * modeling_utils.py:108,120-122.  Epilogue order (each step rounds to bf16 exactly
+ * where the reference's bf16 tensors are materialised):
+ *   v = acc (+bias) -> bf16 ; GELU_TANH / SILU -> bf16 ; SWIGLU: bf16(bf16(silu(g))*u) ;
+ *   RESIDUAL: bf16(v + residual[m,n]) */
+enum {
+    UMV_EPI_BIAS = 1,
+    UMV_EPI_GELU_TANH = 2,
+    UMV_EPI_SILU = 4,
+    UMV_EPI_RESIDUAL = 8,
+    UMV_EPI_SWIGLU = 16, /* packed weight from umv_pack_weight_swiglu_bf16; out is [M, N/2] */
+    UMV_EPI_OUT_F32 = 32 /* store raw fp32 accumulators (+bias), no rounding */
+};
+typedef struct {
+    const uint16_t* x;        /* [M,K] bf16, row stride ldx (elements), K%8==0 */
+    int64_t ldx;
+    const uint16_t* wp;       /* packed weight */
+    const uint16_t* bias;     /* [N] or NULL */
+    const uint16_t* residual; /* [M,N] row stride ldr, or NULL */
+    int64_t ldr;
+    void* out;                /* bf16 (or fp32) [M,N'] row stride ldo */
+    int64_t ldo;
+    const int32_t* row_idx;   /* optional [M]: x, residual and out rows are row_idx[m] (MoT routing,
+                                 qwen2_navit.py:552-562,619-620,891-898) */
+    int M, N, K;
+    int epilogue;
+} umv_gemm_args;
+int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
+
+/* ------------------------------------------------------------------ norms / elementwise */
+/* Qwen2RMSNorm (modeling_qwen2.py:89-94): out = w * bf16(x * rsqrt(mean(x^2)+eps)).
+ * expert (optional, [T] int32): rows with expert[t]!=0 use w_gen (MoT *_moe_gen norms,
+ * qwen2_navit.py:863-865,893-894,1166-1168).  row_idx optional gather/scatter. */
+int umv_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* w_gen, const int32_t* expert,
+                     uint16_t* out, int T, int H, float eps, umv_stream_t stream);
+/* nn.LayerNorm with affine, bf16 in/out, fp32 statistics (siglip_navit.py:283,296,370) */
+int umv_layernorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int T, int H,
+                       float eps, umv_stream_t stream);
+/* nn.Embedding gather (bagel.py:438,577,753,1092,1264): out[t,:] = table[ids[t],:]; optional
+ * out_rows scatter (packed_sequence[packed_text_indexes] = ..., bagel.py:579) */
+int umv_embed_gather_bf16(const uint16_t* table, const int64_t* ids, const int32_t* out_rows, uint16_t* out,
+                          int T, int H, umv_stream_t stream);
+/* out[rows[t],:] = bf16(a[t,:] + table[idx[t],:]) (+ optional second addend broadcast row `bcast`,
+ * added first): connector + vit_pos_embed (bagel.py:590-595), vae2llm + t_emb + pos (bagel.py:1104-1109) */
+int umv_add_rows_bf16(const uint16_t* a, const uint16_t* bcast, const uint16_t* table, const int64_t* idx,
+                      const int32_t* out_rows, uint16_t* out, int T, int H, umv_stream_t stream);
+/* greedy sampling (bagel.py:1301): argmax over bf16 logits, lowest index wins ties */
+int umv_argmax_bf16(const uint16_t* logits, int64_t ld, int64_t* out_ids, int M, int V, umv_stream_t stream);
+/* pixels [N, 3*p*p] fp32 -> bf16 [N, Kp] zero padded (cast that autocast applies before
+ * the patch-embed linear, siglip_navit.py:190) */
+int umv_cast_pad_f32_bf16(const float* x, int64_t ldx, uint16_t* out, int64_t ldo, int T, int K, int Kp,
+                          umv_stream_t stream);
+
+/* ------------------------------------------------------------------ attention
+ * KV slab layout (replaces NaiveCache's re-merged [sum K, kvh, hd] tensors,
+ * qwen2_navit.py:207-221,585-600): per layer
+ *   K  [seg][kv_head][cap][hd]   V^T [seg][kv_head][hd][cap]    (cap % 32 == 0)
+ * V is kept transposed so that P.V consumes 16-byte key-contiguous MFMA fragments. */
+
+/* per-head q/k RMSNorm + RoPE + cast + in-place KV append (qwen2_navit.py:544-545,568-583,
+ * 585-600,622-624; modeling_qwen2.py:196-220).  qkv [T, (nq+2*nkv)*hd] from the fused QKV GEMM.
+ * tok_seg/tok_slot/tok_pos: [T] int32 slab segment, slot in slab, rope position.
+ * expert[t]!=0 -> the *_moe_gen norm weights; fp32_chain!=0 -> the whole call follows the
+ * "gen" rounding chain (norm + rope in fp32, one final cast), as mode=="gen" does for text
+ * and latent tokens alike.
+ * cos/sin tables [max_pos, hd] bf16 as Qwen2RotaryEmbedding returns them (modeling_qwen2.py:184). */
+typedef struct {
+    const uint16_t* qkv;
+    uint16_t* q_out; /* [T, nq, hd] bf16 */
+    uint16_t* k_slab;
+    uint16_t* vt_slab;
+    int64_t k_seg_stride, k_head_stride, v_seg_stride, v_head_stride, v_d_stride;
+    const int32_t *tok_seg, *tok_slot, *tok_pos, *expert;
+    const uint16_t *q_norm_w, *k_norm_w, *q_norm_w_gen, *k_norm_w_gen; /* NULL norm -> no norm/rope (ViT) */
+    const uint16_t *cos_tab, *sin_tab;
+    int T, nq, nkv, hd;
+    float eps;
+    int fp32_chain;
+} umv_qkv_post_args;
+int umv_qkv_post(const umv_qkv_post_args* a, umv_stream_t stream);
+
+/* flash_attn_varlen_func(q,k,v,cu_seqlens_q,cu_seqlens_k,max_q,max_k,causal) as used at
+ * qwen2_navit.py:605-614 and siglip_navit.py:232-241: softmax scale 1/sqrt(hd), fp32
+ * softmax, causal = bottom-right aligned.  Keys come from the slabs; kv_len[s] counts
+ * the keys visible to segment s (including this call's new tokens).  nsplit>1 splits
+ * the key range (decode) and needs workspace of umv_attn_workspace_bytes(). */
+typedef struct {
+    const uint16_t* q; /* [T, nq, hd] */
+    uint16_t* out;     /* [T, nq, hd] */
+    const int32_t* cu_q;
+    const int32_t* kv_len;
+    const uint16_t* k_slab;
+    const uint16_t* vt_slab;
+    int64_t k_seg_stride, k_head_stride, v_seg_stride, v_head_stride, v_d_stride;
+    int nseg, nq, nkv, hd, causal;
+    int max_q;  /* upper bound of query rows per segment (grid sizing) */
+    int max_kv; /* upper bound of kv_len (grid sizing for nsplit) */
+    int nsplit;
+    void* workspace;
+} umv_attn_args;
+size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit);
+int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);
+
+/* decode bookkeeping kept on device so a whole step replays from a hipGraph:
+ * slot[b]+=1, pos[b]+=1, kv_len[b]+=1 (the .tolist() bookkeeping of bagel.py:1266-1275,1303-1310) */
+int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int B, umv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

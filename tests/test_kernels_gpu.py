@@ -1,0 +1,229 @@
+"""Kernel-level parity: each C-ABI entry point against the CPU oracle's restatement of
+the same reference op, on seeded inputs.  Needs an MI355X (-m gpu)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m 'not gpu' on CPU-only machines)")
+    from unimedvl_amd import ops as o
+    return o
+
+
+def ulp_diff(a, b):
+    """distance in bf16 ulps between two bf16 tensors (sign-magnitude ordering)."""
+    def key(t):
+        i = t.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(i >= 0x8000, 0x8000 - i, i)
+    return (key(a) - key(b)).abs()
+
+
+def assert_close_bf16(got, ref, max_ulp=1, frac_exact=0.98, what=""):
+    got, ref = got.cpu(), ref.cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    d = ulp_diff(got, ref)
+    # values near zero can be many "ulps" apart while absolutely tiny: fall back to abs tol there
+    absd = (got.float() - ref.float()).abs()
+    scale = ref.float().abs().max().clamp_min(1e-6)
+    bad = (d > max_ulp) & (absd > scale * 2 ** -8)
+    assert bad.sum() == 0, f"{what}: {int(bad.sum())} elements off by more than {max_ulp} ulp; worst abs {absd.max():.4g}"
+    exact = (d == 0).float().mean().item()
+    assert exact >= frac_exact, f"{what}: only {exact:.4f} bit-exact"
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF16)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 48, 64), (8, 512, 256), (8, 3584, 3584), (16, 4608, 3584), (20, 144, 144),
+                                   (33, 320, 256), (64, 1152, 4304), (7, 100, 72)])
+def test_gemm_skinny(ops, M, N, K):
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, 1 / math.sqrt(K)), rnd((N,), 3)
+    lin = ops.PackedLinear.from_weight(w.cuda(), b.cuda())
+    out = ops.gemm(x.cuda(), lin)
+    ref = (x.float() @ w.float().T + b.float()).to(BF16)
+    assert_close_bf16(out, ref, what=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(65, 128, 64), (200, 320, 256), (1030, 1152, 1152), (300, 144, 208), (2048, 3584, 1152)])
+def test_gemm_tiled(ops, M, N, K):
+    x, w, b = rnd((M, K), 4), rnd((N, K), 5, 1 / math.sqrt(K)), rnd((N,), 6)
+    lin = ops.PackedLinear.from_weight(w.cuda(), b.cuda())
+    out = ops.gemm(x.cuda(), lin)
+    ref = (x.float() @ w.float().T + b.float()).to(BF16)
+    assert_close_bf16(out, ref, what=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M", [8, 40, 300])
+def test_gemm_epilogues(ops, M):
+    K, N, I = 256, 320, 384
+    x = rnd((M, K), 7)
+    w, b, res = rnd((N, K), 8, 1 / 16), rnd((N,), 9), rnd((M, N), 10)
+    lin = ops.PackedLinear.from_weight(w.cuda(), b.cuda())
+    lin_nb = ops.PackedLinear.from_weight(w.cuda())
+    base = x.float() @ w.float().T
+    # bias + gelu_tanh (siglip_navit.py:256-257)
+    out = ops.gemm(x.cuda(), lin, act="gelu_tanh")
+    ref = F.gelu((base + b.float()).to(BF16), approximate="tanh")
+    assert_close_bf16(out, ref, what="gelu")
+    # bias + silu (modeling_utils.py:80-81)
+    out = ops.gemm(x.cuda(), lin, act="silu")
+    assert_close_bf16(out, F.silu((base + b.float()).to(BF16)), what="silu")
+    # residual (qwen2_navit.py:883)
+    out = ops.gemm(x.cuda(), lin_nb, residual=res.cuda())
+    assert_close_bf16(out, res + base.to(BF16), what="residual")
+    # swiglu (modeling_qwen2.py:235)
+    wg, wu = rnd((I, K), 11, 1 / 16), rnd((I, K), 12, 1 / 16)
+    sw = ops.PackedLinear.from_gate_up(wg.cuda(), wu.cuda())
+    out = ops.gemm(x.cuda(), sw)
+    ref = F.silu((x.float() @ wg.float().T).to(BF16)) * (x.float() @ wu.float().T).to(BF16)
+    assert_close_bf16(out, ref, what="swiglu")
+    # row-indexed (MoT routing): rows 1,3,.. of a larger buffer
+    big = rnd((2 * M, K), 13)
+    idx = torch.arange(1, 2 * M, 2, dtype=torch.int32)
+    outbuf = torch.zeros((2 * M, N), dtype=BF16, device="cuda")
+    ops.gemm(big.cuda(), lin, out=outbuf, M=M, row_idx=idx.cuda())
+    ref = torch.zeros((2 * M, N), dtype=BF16)
+    ref[idx.long()] = (big[idx.long()].float() @ w.float().T + b.float()).to(BF16)
+    assert_close_bf16(outbuf, ref, what="row_idx")
+
+
+def test_norms(ops):
+    from oracle.unimedvl_cpu import rmsnorm
+    for T, H in [(8, 3584), (5, 256), (300, 128), (1000, 1152)]:
+        x, w = rnd((T, H), 20, 2.0), (1 + 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(21))).to(BF16)
+        out = ops.rmsnorm(x.cuda(), w.cuda(), 1e-6)
+        assert_close_bf16(out, rmsnorm(x, w, 1e-6), what=f"rmsnorm {T}x{H}", frac_exact=0.995)
+    x = rnd((40, 256), 22)
+    w0, w1 = rnd((256,), 23), rnd((256,), 24)
+    ex = (torch.arange(40) % 3 == 0).to(torch.int32)
+    out = ops.rmsnorm(x.cuda(), w0.cuda(), 1e-6, w_gen=w1.cuda(), expert=ex.cuda())
+    ref = rmsnorm(x, w0, 1e-6)
+    ref[ex.bool()] = rmsnorm(x[ex.bool()], w1, 1e-6)
+    assert_close_bf16(out, ref, what="rmsnorm expert", frac_exact=0.995)
+    for T, H in [(100, 1152), (7, 144)]:
+        x, w, b = rnd((T, H), 25, 1.5), rnd((H,), 26), rnd((H,), 27)
+        out = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+        assert_close_bf16(out, F.layer_norm(x, (H,), w, b, 1e-6), what=f"layernorm {T}x{H}", frac_exact=0.99)
+
+
+def test_gather_add_argmax(ops):
+    table = rnd((500, 256), 30)
+    ids = torch.randint(0, 500, (37,), generator=torch.Generator().manual_seed(31))
+    assert torch.equal(ops.embed_gather(table.cuda(), ids.cuda()).cpu(), table[ids])
+    rows = torch.randperm(60)[:37].to(torch.int32)
+    buf = torch.zeros((60, 256), dtype=BF16, device="cuda")
+    ops.embed_gather(table.cuda(), ids.cuda(), out=buf, out_rows=rows.cuda())
+    ref = torch.zeros((60, 256), dtype=BF16)
+    ref[rows.long()] = table[ids]
+    assert torch.equal(buf.cpu(), ref)
+    a, bc = rnd((37, 256), 32), rnd((256,), 33)
+    out = torch.zeros((60, 256), dtype=BF16, device="cuda")
+    ops.add_rows(a.cuda(), out, bcast=bc.cuda(), table=table.cuda(), idx=ids.cuda(), out_rows=rows.cuda())
+    ref = torch.zeros((60, 256), dtype=BF16)
+    ref[rows.long()] = a + bc + table[ids]
+    assert torch.equal(out.cpu(), ref)
+    logits = rnd((8, 152064), 34)
+    logits[3, 777] = logits[3].max()  # tie: lowest index must win
+    first = int((logits[3] == logits[3].max()).nonzero()[0])
+    got = ops.argmax(logits.cuda()).cpu()
+    assert torch.equal(got, torch.argmax(logits.float(), -1))
+    assert int(got[3]) == first
+    px = torch.randn(10, 588, generator=torch.Generator().manual_seed(35))
+    cp = ops.cast_pad(px.cuda(), 608).cpu()
+    assert torch.equal(cp[:, :588], px.to(BF16)) and (cp[:, 588:] == 0).all()
+
+
+def _rope_tables(max_pos, hd, theta=1e6):
+    from oracle.unimedvl_cpu import rope_cos_sin
+    return rope_cos_sin(torch.arange(max_pos), hd, theta, BF16)
+
+
+@pytest.mark.parametrize("gen", [False, True])
+def test_qkv_post(ops, gen):
+    from oracle.unimedvl_cpu import rmsnorm, apply_rope
+    nq, nkv, hd, T, cap = 4, 2, 128, 11, 64
+    qkv = rnd((T, (nq + 2 * nkv) * hd), 40)
+    qn, kn, qg, kg = (rnd((hd,), 41 + i) + 1 for i in range(4))
+    cos, sin = _rope_tables(4096, hd)
+    pos = torch.tensor([0, 1, 2, 3, 3, 3, 3, 3, 1000, 1001, 4000], dtype=torch.int32)
+    seg = torch.tensor([0] * 6 + [1] * 5, dtype=torch.int32)
+    slot = torch.tensor([3, 4, 5, 6, 7, 8, 0, 1, 2, 3, 4], dtype=torch.int32)
+    expert = (torch.arange(T) % 2).to(torch.int32) if gen else None
+    slab = ops.KVSlab(2, nkv, cap, hd, "cuda")
+    q_out = torch.empty((T, nq, hd), dtype=BF16, device="cuda")
+    ops.qkv_post(qkv.cuda(), q_out, slab, seg.cuda(), slot.cuda(), pos.cuda(), nq, nkv, hd, 1e-6, qn.cuda(), kn.cuda(),
+                 qg.cuda(), kg.cuda(), None if expert is None else expert.cuda(), cos.cuda(), sin.cuda(), fp32_chain=gen)
+    q = qkv[:, :nq * hd].view(T, nq, hd)
+    k = qkv[:, nq * hd:(nq + nkv) * hd].view(T, nkv, hd)
+    v = qkv[:, (nq + nkv) * hd:].view(T, nkv, hd)
+    c, s = cos[pos.long()], sin[pos.long()]
+    if not gen:
+        qr, kr = apply_rope(rmsnorm(q, qn, 1e-6), rmsnorm(k, kn, 1e-6), c, s)
+    else:
+        e = expert.bool()
+        qf, kf = q.float(), k.float()
+        qf[~e] = rmsnorm(qf[~e], qn, 1e-6); qf[e] = rmsnorm(qf[e], qg, 1e-6)
+        kf[~e] = rmsnorm(kf[~e], kn, 1e-6); kf[e] = rmsnorm(kf[e], kg, 1e-6)
+        # text tokens of a gen-mode call take the fp32 chain too (qwen2_navit.py:568-579)
+        qr, kr = apply_rope(qf, kf, c, s)
+    assert_close_bf16(q_out, qr.to(BF16), what="q", frac_exact=0.99)
+    kc, vtc = slab.k.cpu(), slab.vt.cpu()
+    for t in range(T):
+        assert_close_bf16(kc[seg[t], :, slot[t]], kr[t].to(BF16), what=f"k[{t}]", frac_exact=0.97)
+        assert torch.equal(vtc[seg[t], :, :, slot[t]], v[t])
+
+
+def _attn_case(ops, nq, nkv, hd, q_lens, k_lens, causal, nsplit=1, seed=50):
+    from oracle.unimedvl_cpu import attention_segment
+    nseg = len(q_lens)
+    cap = (max(k_lens) + 31) // 32 * 32
+    slab = ops.KVSlab(nseg, nkv, cap, hd, "cuda")
+    T = sum(q_lens)
+    q = rnd((T, nq, hd), seed)
+    ks = [rnd((lk, nkv, hd), seed + 1 + i) for i, lk in enumerate(k_lens)]
+    vs = [rnd((lk, nkv, hd), seed + 100 + i) for i, lk in enumerate(k_lens)]
+    kh, vh = slab.k.cpu(), slab.vt.cpu()
+    kh += float("nan") if False else 0
+    for i, lk in enumerate(k_lens):
+        kh[i, :, :lk] = ks[i].transpose(0, 1)
+        vh[i, :, :, :lk] = vs[i].permute(1, 2, 0)
+    slab.k.copy_(kh); slab.vt.copy_(vh)
+    cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32)
+    out = torch.zeros((T, nq, hd), dtype=BF16, device="cuda")
+    ws = ops.attn_workspace(nseg, nq, hd, max(q_lens), nsplit, "cuda") if nsplit > 1 else None
+    ops.attention(q.cuda(), out, slab, cu.cuda(), torch.tensor(k_lens, dtype=torch.int32).cuda(), nq, nkv, hd, causal,
+                  max(q_lens), max(k_lens), nsplit, ws)
+    ref = torch.empty_like(q)
+    t0 = 0
+    for i, lq in enumerate(q_lens):
+        ref[t0:t0 + lq] = attention_segment(q[t0:t0 + lq], ks[i], vs[i], causal, impl="flash")
+        t0 += lq
+    got = out.cpu()
+    err = (got.float() - ref.float()).abs().max().item()
+    assert err < 0.03, f"attention max abs err {err}"
+    assert_close_bf16(got, ref, max_ulp=4, frac_exact=0.5, what="attention")
+
+
+def test_attention_prefill(ops):
+    _attn_case(ops, 28, 4, 128, [34, 130], [34 + 50, 130], causal=True)
+    _attn_case(ops, 28, 4, 128, [70, 9], [70, 9 + 40], causal=False)
+    _attn_case(ops, 2, 1, 128, [14, 33], [14, 33 + 14], causal=True)
+    _attn_case(ops, 16, 16, 72, [100, 37, 16], [100, 37, 16], causal=False)
+    _attn_case(ops, 2, 2, 72, [12], [12], causal=False)
+
+
+def test_attention_decode_split(ops):
+    _attn_case(ops, 28, 4, 128, [1] * 8, [1061, 1070, 33, 1, 500, 777, 1572, 64], causal=True, nsplit=1)
+    _attn_case(ops, 28, 4, 128, [1] * 8, [1061, 1070, 33, 1, 500, 777, 1572, 64], causal=True, nsplit=8)
+    _attn_case(ops, 2, 1, 128, [1, 1], [20, 45], causal=True, nsplit=4)

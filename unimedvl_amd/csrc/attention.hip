@@ -1,0 +1,235 @@
+// Varlen GQA attention over KV slabs (flash-style, online softmax, fp32 statistics).
+//
+// One wavefront owns a tile of 16 "rows".  A row is a (query, q-head-of-the-GQA-group)
+// pair, so the G = nq/nkv heads that share a KV head share every K/V fragment load:
+//   prefill, G=7 : 2 queries x 7 heads per tile        decode (Lq=1): the 7 heads
+//   ViT,     G=1 : 16 queries per tile
+// Per 32-key block (MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+//   S^T[key][row] = K . Q^T   A = K rows (key order permuted so that each lane ends up
+//                             with 8 CONSECUTIVE keys), B = Q^T (held in registers)
+//   O^T[d][row]  += V^T . P^T A = V^T fragment = 16 B contiguous along keys (the slab keeps
+//                             V transposed), B = P^T = the lane's own 8 probabilities
+// so P never moves between lanes, the O rescale factor is lane-local, and no LDS is used.
+// nsplit > 1 splits the key range over workgroups (decode) and a combine kernel merges.
+#include "common.h"
+#include "../../include/unimedvl_hip.h"
+
+__device__ __forceinline__ bf16x8 mask_keys(bf16x8 v, int nvalid) {
+    // keep the first nvalid (0..8) bf16 elements, zero the rest
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = j < nvalid ? v[j] : (short)0;
+    return o;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_log2e) {
+    constexpr int KS = (HD + 31) / 32;   // k-steps over the head dim for S
+    constexpr int DT = (HD + 15) / 16;   // 16-wide output d tiles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int G = a.nq / a.nkv;
+    const int QPT = 16 / G > 0 ? 16 / G : 1;
+    const int s = blockIdx.z;
+    const int kh = blockIdx.y % a.nkv;
+    const int split = blockIdx.y / a.nkv;
+    const int qt = blockIdx.x * 4 + wave;
+    const int q0 = a.cu_q[s];
+    const int Lq = a.cu_q[s + 1] - q0;
+    const int Lk = a.kv_len[s];
+    if (qt * QPT >= Lq) return;
+
+    const int ql = j / G, hg = j % G;
+    const int qi = qt * QPT + ql;
+    const bool rvalid = (j < G * QPT) && (qi < Lq);
+    const int head = kh * G + hg;
+    // causal = bottom-right aligned: query qi sees keys <= Lk - Lq + qi
+    const int limit = a.causal ? (Lk - Lq + qi) : (Lk - 1);
+
+    // Q fragments (B operand): lane (j,g) holds Q[row j][ks*32 + g*8 .. +8]
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qp = a.q + ((int64_t)(q0 + (rvalid ? qi : 0)) * a.nq + head) * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            qf[ks] = (rvalid && d < HD) ? ldg_frag(qp + d) : zero_frag();
+        }
+    }
+    // key range of this split, in 32-key blocks
+    int kb_begin = 0, kb_end = Lk;
+    if (a.nsplit > 1) {
+        int chunk = ((Lk + a.nsplit - 1) / a.nsplit + 31) & ~31;
+        kb_begin = split * chunk;
+        kb_end = min(Lk, kb_begin + chunk);
+    }
+    if (a.causal) {  // no key beyond the tile's largest limit
+        int last_q = min(Lq - 1, qt * QPT + QPT - 1);
+        kb_end = min(kb_end, Lk - Lq + last_q + 1);
+    }
+    const bf16_t* kbase = a.k_slab + s * a.k_seg_stride + kh * a.k_head_stride;
+    const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kb = kb_begin; kb < kb_end; kb += 32) {
+        // ---- S^T = K Q^T; A row i=(lane&15) of tile t  <->  key kb + (i>>2)*8 + t*4 + (i&3)
+        f32x4 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
+            const bf16_t* kp = kbase + (int64_t)key * HD;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d = ks * 32 + g * 8;
+                bf16x8 kf = (d < HD) ? ldg_frag(kp + d) : zero_frag();
+                st[t] = mfma16(kf, qf[ks], st[t]);
+            }
+        }
+        // lane (row j, g) now holds scores of keys kb + g*8 + t*4 + r
+        float sc[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + g * 8 + t * 4 + r;
+                float v = st[t][r] * scale_log2e;
+                v = (key <= limit && key < kb_end) ? v : -INFINITY;
+                sc[t * 4 + r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+        float ps = 0.f;
+        bf16x8 pf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float p = exp2f(sc[i] - m_use);   // exp2(-inf) = 0
+            bf16_t pb = f2bf(p);
+            ps += p;
+            pf[i] = (short)pb;
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        // ---- O^T += V^T P^T ; A = V^T[d = dt*16 + (lane&15)][kb + g*8 .. +8]
+        const bool partial = kb + 32 > Lk;
+        const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + j;
+            bf16x8 vf = (d < HD) ? ldg_frag(vbase + (int64_t)d * a.v_d_stride + kb + g * 8) : zero_frag();
+            if (partial) vf = mask_keys(vf, nvalid);
+            f32x4 acc = o[dt];
+            acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+            o[dt] = mfma16(vf, pf, acc);
+        }
+    }
+    if (!rvalid) return;
+    const int64_t tok = q0 + qi;
+    if (a.nsplit == 1) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* op = a.out + (tok * a.nq + head) * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d + 3 < HD) {
+                u32x2 pk;
+                pk.x = pack2bf(o[dt].x * inv, o[dt].y * inv);
+                pk.y = pack2bf(o[dt].z * inv, o[dt].w * inv);
+                *reinterpret_cast<u32x2*>(op + d) = pk;
+            }
+        }
+    } else {
+        float* wsO = reinterpret_cast<float*>(a.workspace);
+        const int64_t slotw = (tok * a.nq + head) * a.nsplit + split;
+        float* po = wsO + slotw * (HD + 4);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d + 3 < HD) *reinterpret_cast<f32x4*>(po + d) = o[dt];
+        }
+        if (g == 0) { po[HD] = m_run; po[HD + 1] = l_run; }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
+                                                           const int32_t* __restrict__ cu_q, int nseg, int nq, int nsplit) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (tok*nq + head)
+    if (row >= (int64_t)cu_q[nseg] * nq) return;
+    const float* base = ws + row * nsplit * (HD + 4);
+    float M = -INFINITY;
+    for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, base[sidx * (HD + 4) + HD]);
+    float L = 0.f;
+    float acc[(HD + 63) / 64];
+#pragma unroll
+    for (int i = 0; i < (HD + 63) / 64; ++i) acc[i] = 0.f;
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+        const float* p = base + sidx * (HD + 4);
+        const float m = p[HD], l = p[HD + 1];
+        const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
+        L += w * l;
+#pragma unroll
+        for (int i = 0; i < (HD + 63) / 64; ++i) {
+            int d = i * 64 + lane;
+            if (d < HD && w > 0.f) acc[i] += w * p[d];
+        }
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+#pragma unroll
+    for (int i = 0; i < (HD + 63) / 64; ++i) {
+        int d = i * 64 + lane;
+        if (d < HD) out[row * HD + d] = f2bf(acc[i] * inv);
+    }
+}
+
+extern "C" size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit) {
+    if (nsplit <= 1) return 0;
+    return (size_t)nseg * max_q * nq * nsplit * (hd + 4) * sizeof(float);
+}
+
+extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
+    UMV_CHECK(ap, UMV_ERR_ARG, "attn: null args");
+    const umv_attn_args& a = *ap;
+    UMV_CHECK(a.q && a.out && a.cu_q && a.kv_len && a.k_slab && a.vt_slab, UMV_ERR_ARG, "attn: null pointer");
+    UMV_CHECK(a.nkv > 0 && a.nq % a.nkv == 0 && a.nq / a.nkv <= 16, UMV_ERR_ARG, "attn: bad head counts nq=%d nkv=%d", a.nq, a.nkv);
+    UMV_CHECK(a.nsplit >= 1 && (a.nsplit == 1 || a.workspace), UMV_ERR_ARG, "attn: nsplit=%d needs workspace", a.nsplit);
+    UMV_CHECK((a.v_d_stride % 8) == 0, UMV_ERR_ARG, "attn: slab capacity must be a multiple of 8");
+    if (a.nseg == 0 || a.max_q == 0) return UMV_OK;
+    const int G = a.nq / a.nkv;
+    const int QPT = 16 / G > 0 ? 16 / G : 1;
+    const int qtiles = (a.max_q + QPT - 1) / QPT;
+    dim3 grid((qtiles + 3) / 4, a.nkv * a.nsplit, a.nseg), block(256);
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)a.hd);
+    hipStream_t s = (hipStream_t)stream;
+    if (a.hd == 128)
+        hipLaunchKernelGGL((attn_kernel<128>), grid, block, 0, s, a, scale_log2e);
+    else if (a.hd == 72)
+        hipLaunchKernelGGL((attn_kernel<72>), grid, block, 0, s, a, scale_log2e);
+    else
+        UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "attn: head_dim %d unsupported (128, 72)", a.hd);
+    UMV_LAUNCH_CHECK();
+    if (a.nsplit > 1) {
+        // grid over the static bound nseg*max_q tokens; rows beyond cu_q[nseg]*nq exit on device
+        int64_t rows = (int64_t)a.nseg * a.max_q * a.nq;
+        if (a.hd == 128)
+            hipLaunchKernelGGL((attn_combine_kernel<128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                               (const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.nsplit);
+        else
+            hipLaunchKernelGGL((attn_combine_kernel<72>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                               (const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.nsplit);
+        UMV_LAUNCH_CHECK();
+    }
+    return UMV_OK;
+}

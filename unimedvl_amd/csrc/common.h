@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libunimedvl_hip.
+// Wave = 64 lanes everywhere.  bf16 is carried as raw uint16_t bit patterns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // one 16x16 MFMA C/D fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define UMV_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (same result as torch's .to(bfloat16) for finite values; NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// 1/sqrt(x) with correctly rounded sqrt and divide (what torch.rsqrt does on CPU)
+__device__ __forceinline__ float rsqrt_ieee(float x) { return __fdiv_rn(1.0f, __fsqrt_rn(x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// 16-byte global load of 8 bf16 as an MFMA fragment
+__device__ __forceinline__ bf16x8 ldg_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 zero_frag() { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+
+// error plumbing (host side)
+void umv_set_error(const char* fmt, ...);
+#define UMV_CHECK(cond, code, ...)            \
+    do {                                      \
+        if (!(cond)) {                        \
+            umv_set_error(__VA_ARGS__);       \
+            return (code);                    \
+        }                                     \
+    } while (0)
+#define UMV_LAUNCH_CHECK()                                            \
+    do {                                                              \
+        hipError_t e__ = hipGetLastError();                           \
+        if (e__ != hipSuccess) {                                      \
+            umv_set_error("launch failed: %s", hipGetErrorString(e__)); \
+            return UMV_ERR_LAUNCH;                                    \
+        }                                                             \
+    } while (0)
+
+enum { UMV_OK = 0, UMV_ERR_ARG = -1, UMV_ERR_LAUNCH = -2, UMV_ERR_UNSUPPORTED = -3 };

@@ -1,0 +1,364 @@
+// HBM-bound row kernels: norms, gathers, q/k-norm + RoPE + KV append, argmax.
+// One wavefront per row (or per head); 16-byte bf16x8 accesses; wave64 shuffles.
+#include "common.h"
+#include "../../include/unimedvl_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+// ----------------------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void umv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* umv_last_error(void) { return g_err; }
+extern "C" int umv_version(void) { return 100; }
+
+// ----------------------------------------------------------------------------- RMSNorm
+// modeling_qwen2.py:89-94: h = x.float(); h = h * rsqrt(mean(h^2) + eps); out = w * h.to(bf16)
+// 4 waves per block, one row per wave; row held in registers when H <= 64*8*MAXV.
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                      const bf16_t* __restrict__ wg, const int32_t* __restrict__ expert,
+                                                      bf16_t* __restrict__ out, int T, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const bf16_t* xr = x + (int64_t)row * H;
+    const bf16_t* wr = (expert && expert[row]) ? wg : w;
+    bf16x8 v[MAXV];
+    float ss = 0.f;
+    const int nv = H / 8;  // H % 8 == 0
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = i * 64 + lane;
+        if (c < nv) {
+            v[i] = ldg_frag(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = bf2f((bf16_t)v[i][j]);
+                ss += f * f;
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrt_ieee(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = i * 64 + lane;
+        if (c < nv) {
+            bf16x8 ww = ldg_frag(wr + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float h = rbf(bf2f((bf16_t)v[i][j]) * rstd);
+                o[j] = (short)f2bf(bf2f((bf16_t)ww[j]) * h);
+            }
+            *reinterpret_cast<bf16x8*>(out + (int64_t)row * H + c * 8) = o;
+        }
+    }
+}
+
+extern "C" int umv_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* w_gen, const int32_t* expert,
+                                uint16_t* out, int T, int H, float eps, umv_stream_t stream) {
+    UMV_CHECK(x && w && out, UMV_ERR_ARG, "rmsnorm: null pointer");
+    UMV_CHECK(H % 8 == 0 && H <= 64 * 8 * 16, UMV_ERR_ARG, "rmsnorm: H=%d unsupported", H);
+    UMV_CHECK(!expert || w_gen, UMV_ERR_ARG, "rmsnorm: expert routing without w_gen");
+    if (T == 0) return UMV_OK;
+    dim3 grid((T + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 512 * 2)
+        hipLaunchKernelGGL((rmsnorm_kernel<2>), grid, block, 0, s, x, w, w_gen, expert, out, T, H, eps);
+    else if (H <= 512 * 8)
+        hipLaunchKernelGGL((rmsnorm_kernel<8>), grid, block, 0, s, x, w, w_gen, expert, out, T, H, eps);
+    else
+        hipLaunchKernelGGL((rmsnorm_kernel<16>), grid, block, 0, s, x, w, w_gen, expert, out, T, H, eps);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- LayerNorm
+// F.layer_norm on bf16 (siglip_navit.py:283,296,370): fp32 statistics, one rounding to bf16.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ out, int T, int H,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const bf16_t* xr = x + (int64_t)row * H;
+    bf16x8 v[MAXV];
+    float s = 0.f;
+    const int nv = H / 8;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = i * 64 + lane;
+        if (c < nv) {
+            v[i] = ldg_frag(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += bf2f((bf16_t)v[i][j]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = i * 64 + lane;
+        if (c < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float d = bf2f((bf16_t)v[i][j]) - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrt_ieee(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = i * 64 + lane;
+        if (c < nv) {
+            bf16x8 ww = ldg_frag(w + c * 8), bb = ldg_frag(b + c * 8), o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = (short)f2bf((bf2f((bf16_t)v[i][j]) - mean) * rstd * bf2f((bf16_t)ww[j]) + bf2f((bf16_t)bb[j]));
+            *reinterpret_cast<bf16x8*>(out + (int64_t)row * H + c * 8) = o;
+        }
+    }
+}
+
+extern "C" int umv_layernorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int T, int H,
+                                  float eps, umv_stream_t stream) {
+    UMV_CHECK(x && w && b && out, UMV_ERR_ARG, "layernorm: null pointer");
+    UMV_CHECK(H % 8 == 0 && H <= 64 * 8 * 8, UMV_ERR_ARG, "layernorm: H=%d unsupported", H);
+    if (T == 0) return UMV_OK;
+    dim3 grid((T + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 512 * 3)
+        hipLaunchKernelGGL((layernorm_kernel<3>), grid, block, 0, s, x, w, b, out, T, H, eps);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, w, b, out, T, H, eps);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- embedding gather / add rows
+__global__ __launch_bounds__(256) void embed_gather_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ out_rows, bf16_t* __restrict__ out, int T,
+                                                           int H) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const bf16_t* src = table + ids[t] * (int64_t)H;
+    bf16_t* dst = out + (int64_t)(out_rows ? out_rows[t] : t) * H;
+    for (int c = lane; c < H / 8; c += 64) *reinterpret_cast<bf16x8*>(dst + c * 8) = ldg_frag(src + c * 8);
+}
+
+extern "C" int umv_embed_gather_bf16(const uint16_t* table, const int64_t* ids, const int32_t* out_rows, uint16_t* out, int T,
+                                     int H, umv_stream_t stream) {
+    UMV_CHECK(table && ids && out && H % 8 == 0, UMV_ERR_ARG, "embed_gather: bad args");
+    if (T == 0) return UMV_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, out_rows, out, T, H);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ bcast,
+                                                       const bf16_t* __restrict__ table, const int64_t* __restrict__ idx,
+                                                       const int32_t* __restrict__ out_rows, bf16_t* __restrict__ out, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const bf16_t* ar = a + (int64_t)t * H;
+    const bf16_t* tr = table ? table + idx[t] * (int64_t)H : nullptr;
+    bf16_t* dst = out + (int64_t)(out_rows ? out_rows[t] : t) * H;
+    for (int c = lane; c < H / 8; c += 64) {
+        bf16x8 va = ldg_frag(ar + c * 8), o;
+        bf16x8 vb = bcast ? ldg_frag(bcast + c * 8) : zero_frag();
+        bf16x8 vt = tr ? ldg_frag(tr + c * 8) : zero_frag();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf2f((bf16_t)va[j]);
+            if (bcast) f = rbf(f + bf2f((bf16_t)vb[j]));
+            if (tr) f = rbf(f + bf2f((bf16_t)vt[j]));
+            o[j] = (short)f2bf(f);
+        }
+        *reinterpret_cast<bf16x8*>(dst + c * 8) = o;
+    }
+}
+
+extern "C" int umv_add_rows_bf16(const uint16_t* a, const uint16_t* bcast, const uint16_t* table, const int64_t* idx,
+                                 const int32_t* out_rows, uint16_t* out, int T, int H, umv_stream_t stream) {
+    UMV_CHECK(a && out && H % 8 == 0, UMV_ERR_ARG, "add_rows: bad args");
+    UMV_CHECK(!table || idx, UMV_ERR_ARG, "add_rows: table without idx");
+    if (T == 0) return UMV_OK;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, bcast, table, idx, out_rows, out, T, H);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- argmax (bf16 logits, lowest index wins)
+__global__ __launch_bounds__(1024) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t ld, int64_t* __restrict__ out, int V) {
+    __shared__ float smax[16];
+    __shared__ int sidx[16];
+    const int m = blockIdx.x;
+    const bf16_t* row = logits + (int64_t)m * ld;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    const int nv = V / 8;
+    for (int c = threadIdx.x; c < nv; c += blockDim.x) {
+        bf16x8 v = ldg_frag(row + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf2f((bf16_t)v[j]);
+            int i = c * 8 + j;
+            if (f > best || (f == best && i < bidx) || (f != f && !(best != best))) { best = f; bidx = i; }
+        }
+    }
+    for (int i = nv * 8 + threadIdx.x; i < V; i += blockDim.x) {
+        float f = bf2f(row[i]);
+        if (f > best || (f == best && i < bidx)) { best = f; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { smax[wave] = best; sidx[wave] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (smax[w] > best || (smax[w] == best && sidx[w] < bidx)) { best = smax[w]; bidx = sidx[w]; }
+        out[m] = bidx;
+    }
+}
+
+extern "C" int umv_argmax_bf16(const uint16_t* logits, int64_t ld, int64_t* out_ids, int M, int V, umv_stream_t stream) {
+    UMV_CHECK(logits && out_ids && V > 0 && (ld % 8) == 0, UMV_ERR_ARG, "argmax: bad args");
+    if (M == 0) return UMV_OK;
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, out_ids, V);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- fp32 -> bf16 with zero padding
+__global__ void cast_pad_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int T, int K, int Kp) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)T * Kp) return;
+    int t = (int)(gid / Kp), k = (int)(gid % Kp);
+    out[(int64_t)t * ldo + k] = k < K ? f2bf(x[(int64_t)t * ldx + k]) : (bf16_t)0;
+}
+extern "C" int umv_cast_pad_f32_bf16(const float* x, int64_t ldx, uint16_t* out, int64_t ldo, int T, int K, int Kp,
+                                     umv_stream_t stream) {
+    UMV_CHECK(x && out && Kp >= K, UMV_ERR_ARG, "cast_pad: bad args");
+    if (T == 0) return UMV_OK;
+    int64_t total = (int64_t)T * Kp;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, T, K, Kp);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- q/k norm + RoPE + KV append
+// One wavefront per (token, head) over the nq + 2*nkv heads of the fused QKV row.
+// Lane i owns elements i*EPL.. of the first half and the matching ones of the second
+// half (rotate_half pairs x[d] with x[d + hd/2], modeling_qwen2.py:188-192).
+// und chain (bf16 tensors, qwen2_navit.py:544-545,576-583):
+//    n = bf16(w * bf16(x*rstd));  out = bf16(bf16(n*cos) + bf16(rot(n)*sin))
+// gen chain (fp32 tensors, qwen2_navit.py:568-583):
+//    n = w * (x*rstd);  out = bf16(n*cos + rot(n)*sin)      (cos/sin are bf16 values)
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
+    constexpr int HALF = HD / 2;
+    const int lane = threadIdx.x & 63;
+    const int nheads = a.nq + 2 * a.nkv;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (int64_t)a.T * nheads) return;
+    const int t = (int)(item / nheads);
+    const int h = (int)(item % nheads);
+    const bf16_t* src = a.qkv + (int64_t)t * nheads * HD + (int64_t)h * HD;
+    const int seg = a.tok_seg[t], slot = a.tok_slot[t];
+    const bool is_q = h < a.nq, is_k = !is_q && h < a.nq + a.nkv;
+    const bool act = lane < HALF;  // HD=128: all 64 lanes; HD=72: 36 lanes
+    float x1 = 0.f, x2 = 0.f;
+    if (act) { x1 = bf2f(src[lane]); x2 = bf2f(src[lane + HALF]); }
+    if (!is_q && !is_k) {  // V head: transposed store V^T[seg][kvh][d][slot]
+        const int kvh = h - a.nq - a.nkv;
+        bf16_t* dst = a.vt_slab + seg * a.v_seg_stride + kvh * a.v_head_stride + slot;
+        if (act) {
+            dst[(int64_t)lane * a.v_d_stride] = f2bf(x1);
+            dst[(int64_t)(lane + HALF) * a.v_d_stride] = f2bf(x2);
+        }
+        return;
+    }
+    float o1 = x1, o2 = x2;
+    const bf16_t* nw = is_q ? a.q_norm_w : a.k_norm_w;
+    if (nw) {
+        const bool gen = a.fp32_chain != 0;
+        if (a.expert && a.expert[t]) nw = is_q ? a.q_norm_w_gen : a.k_norm_w_gen;
+        float ss = wave_sum(x1 * x1 + x2 * x2);
+        const float rstd = rsqrt_ieee(ss / (float)HD + a.eps);
+        const int pos = a.tok_pos[t];
+        float c1 = 0.f, s1 = 0.f, c2 = 0.f, s2 = 0.f, w1 = 0.f, w2 = 0.f;
+        if (act) {
+            c1 = bf2f(a.cos_tab[(int64_t)pos * HD + lane]);
+            s1 = bf2f(a.sin_tab[(int64_t)pos * HD + lane]);
+            c2 = bf2f(a.cos_tab[(int64_t)pos * HD + lane + HALF]);
+            s2 = bf2f(a.sin_tab[(int64_t)pos * HD + lane + HALF]);
+            w1 = bf2f(nw[lane]);
+            w2 = bf2f(nw[lane + HALF]);
+        }
+        if (!gen) {
+            float n1 = rbf(w1 * rbf(x1 * rstd));
+            float n2 = rbf(w2 * rbf(x2 * rstd));
+            o1 = rbf(rbf(n1 * c1) + rbf(-n2 * s1));
+            o2 = rbf(rbf(n2 * c2) + rbf(n1 * s2));
+        } else {
+            float n1 = __fmul_rn(w1, __fmul_rn(x1, rstd));
+            float n2 = __fmul_rn(w2, __fmul_rn(x2, rstd));
+            o1 = __fadd_rn(__fmul_rn(n1, c1), __fmul_rn(-n2, s1));
+            o2 = __fadd_rn(__fmul_rn(n2, c2), __fmul_rn(n1, s2));
+        }
+    }
+    if (is_q) {
+        bf16_t* dst = a.q_out + (int64_t)t * a.nq * HD + (int64_t)h * HD;
+        if (act) { dst[lane] = f2bf(o1); dst[lane + HALF] = f2bf(o2); }
+    } else {
+        const int kvh = h - a.nq;
+        bf16_t* dst = a.k_slab + seg * a.k_seg_stride + kvh * a.k_head_stride + (int64_t)slot * HD;
+        if (act) { dst[lane] = f2bf(o1); dst[lane + HALF] = f2bf(o2); }
+    }
+}
+
+extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
+    UMV_CHECK(ap, UMV_ERR_ARG, "qkv_post: null args");
+    const umv_qkv_post_args& a = *ap;
+    UMV_CHECK(a.qkv && a.q_out && a.k_slab && a.vt_slab && a.tok_seg && a.tok_slot, UMV_ERR_ARG, "qkv_post: null pointer");
+    UMV_CHECK(!a.q_norm_w || (a.k_norm_w && a.cos_tab && a.sin_tab && a.tok_pos), UMV_ERR_ARG, "qkv_post: norm without rope tables");
+    UMV_CHECK(!a.expert || (a.q_norm_w_gen && a.k_norm_w_gen), UMV_ERR_ARG, "qkv_post: expert routing without gen norms");
+    if (a.T == 0) return UMV_OK;
+    int64_t items = (int64_t)a.T * (a.nq + 2 * a.nkv);
+    dim3 grid((unsigned)((items + 3) / 4)), block(256);
+    if (a.hd == 128)
+        hipLaunchKernelGGL((qkv_post_kernel<128>), grid, block, 0, (hipStream_t)stream, a);
+    else if (a.hd == 72)
+        hipLaunchKernelGGL((qkv_post_kernel<72>), grid, block, 0, (hipStream_t)stream, a);
+    else
+        UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "qkv_post: head_dim %d unsupported (128, 72)", a.hd);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+__global__ void decode_advance_kernel(int32_t* slot, int32_t* pos, int32_t* kv_len, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { slot[b] += 1; pos[b] += 1; kv_len[b] += 1; }
+}
+extern "C" int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int B, umv_stream_t stream) {
+    UMV_CHECK(tok_slot && tok_pos && kv_len, UMV_ERR_ARG, "decode_advance: null pointer");
+    if (B == 0) return UMV_OK;
+    hipLaunchKernelGGL(decode_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tok_slot, tok_pos, kv_len, B);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}

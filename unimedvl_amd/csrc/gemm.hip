@@ -1,0 +1,415 @@
+// GEMM family for libunimedvl_hip (gfx950).  out[m,n] = epi(sum_k x[m,k] W[n,k]).
+//
+// W is pre-tiled (umv_pack_weight_bf16) into MFMA A-fragment order so that one
+// wavefront instruction fetches a whole 16(n) x 32(k) tile as 1 KiB contiguous:
+//   P[nt][kt][lane][8],  lane = g*16 + r,  element j  <->  W[nt*16 + r][kt*32 + g*8 + j]
+// With W as the A operand and x^T as the B operand of v_mfma_f32_16x16x32_bf16 the
+// accumulator of lane (r,g) holds out[m = r][n = g*4 + reg]: four consecutive n per
+// lane, i.e. one 8-byte bf16x4 store per 16x16 tile.
+//
+// Two kernels:
+//   * gemm_skinny  (M <= 64, decode / MoT text rows): HBM-bound weight streaming.
+//     One workgroup = NT n-tiles x all of K; its 8 waves split K and reduce through
+//     LDS (deterministic, no atomics, no inter-workgroup split-K).  Weight fragments
+//     go straight from HBM to VGPRs (no LDS round trip: each byte is used once).
+//   * gemm_tiled   (M > 64, prefill / ViT / diffusion): 128x128 workgroup tile,
+//     4 waves of 64x64, W fragments from the packed stream, x staged through LDS.
+#include "common.h"
+#include "../../include/unimedvl_hip.h"
+
+// ----------------------------------------------------------------------------- packing
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ p, int N, int K, int NTT,
+                                   int KT, int interleave_I, const bf16_t* __restrict__ w2) {
+    // one thread per 8-element group of the packed image
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)NTT * KT * 64;
+    if (gid >= total) return;
+    int lane = (int)(gid & 63);
+    int64_t tile = gid >> 6;
+    int kt = (int)(tile % KT);
+    int nt = (int)(tile / KT);
+    int r = lane & 15, g = lane >> 4;
+    int k = kt * 32 + g * 8;
+    const bf16_t* src = w;
+    int n;
+    if (interleave_I > 0) {  // swiglu: even tiles gate, odd tiles up
+        int t = nt >> 1;
+        n = t * 16 + r;
+        src = (nt & 1) ? w2 : w;
+        if (n >= interleave_I) n = -1;
+    } else {
+        n = nt * 16 + r;
+        if (n >= N) n = -1;
+    }
+    bf16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (n >= 0 && k + j < K) ? src[(int64_t)n * K + k + j] : (bf16_t)0;
+    u32x4 o;
+    o.x = v[0] | ((uint32_t)v[1] << 16);
+    o.y = v[2] | ((uint32_t)v[3] << 16);
+    o.z = v[4] | ((uint32_t)v[5] << 16);
+    o.w = v[6] | ((uint32_t)v[7] << 16);
+    *reinterpret_cast<u32x4*>(p + gid * 8) = o;
+}
+
+extern "C" size_t umv_packed_weight_elems(int N, int K) {
+    size_t ntt = (size_t)(N + 15) / 16, kt = (size_t)(K + 31) / 32;
+    return ntt * kt * 512;
+}
+
+extern "C" int umv_pack_weight_bf16(const uint16_t* w, uint16_t* packed, int N, int K, umv_stream_t stream) {
+    UMV_CHECK(w && packed && N > 0 && K > 0, UMV_ERR_ARG, "pack_weight: bad args");
+    int NTT = (N + 15) / 16, KT = (K + 31) / 32;
+    int64_t total = (int64_t)NTT * KT * 64;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, N, K, NTT, KT, 0,
+                       (const bf16_t*)nullptr);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+extern "C" int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int I, int K,
+                                           umv_stream_t stream) {
+    UMV_CHECK(gate && up && packed && I > 0 && K > 0, UMV_ERR_ARG, "pack_weight_swiglu: bad args");
+    int NTT = 2 * ((I + 15) / 16), KT = (K + 31) / 32;
+    int64_t total = (int64_t)NTT * KT * 64;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gate, packed, 2 * I, K, NTT,
+                       KT, I, up);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- epilogue math
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+    const float kKappa = 0.044715f;
+    float x3 = x * x * x;
+    float inner = kBeta * (x + kKappa * x3);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+struct EpiCtx {
+    const bf16_t* bias;
+    const bf16_t* residual;
+    int64_t ldr;
+    void* out;
+    int64_t ldo;
+    int N;       // logical N of the GEMM (2I for swiglu)
+    int flags;
+};
+
+// Finish 4 consecutive n (n0..n0+3) of row `orow` from fp32 accumulators.
+__device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0, float v0, float v1, float v2, float v3) {
+    float v[4] = {v0, v1, v2, v3};
+    if (e.flags & UMV_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j < e.N) v[j] += bf2f(e.bias[n0 + j]);
+    }
+    if (e.flags & UMV_EPI_OUT_F32) {
+        float* o = reinterpret_cast<float*>(e.out) + orow * e.ldo + n0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j < e.N) o[j] = v[j];
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = rbf(v[j]);
+    if (e.flags & UMV_EPI_GELU_TANH) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rbf(gelu_tanh_f(v[j]));
+    }
+    if (e.flags & UMV_EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rbf(silu_f(v[j]));
+    }
+    if (e.flags & UMV_EPI_RESIDUAL) {
+        const bf16_t* rr = e.residual + orow * e.ldr + n0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j < e.N) v[j] = rbf(v[j] + bf2f(rr[j]));
+    }
+    bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + n0;
+    if (n0 + 3 < e.N && ((e.ldo & 3) == 0)) {
+        u32x2 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(o) = pk;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j < e.N) o[j] = f2bf(v[j]);
+    }
+}
+
+// SwiGLU: g,u accumulators of the same 4 output columns -> act[orow][c0..c0+3]
+__device__ __forceinline__ void epi_swiglu4(const EpiCtx& e, int64_t orow, int c0, int I, const float* g, const float* u) {
+    bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + c0;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float gg = rbf(g[j]), uu = rbf(u[j]);
+        v[j] = rbf(rbf(silu_f(gg)) * uu);   // act_fn(gate) -> bf16, * up -> bf16 (modeling_qwen2.py:235)
+    }
+    if (c0 + 3 < I && ((e.ldo & 3) == 0)) {
+        u32x2 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(o) = pk;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < I) o[j] = f2bf(v[j]);
+    }
+}
+
+// ----------------------------------------------------------------------------- skinny (M <= 64)
+#define SK_WAVES 8
+template <int MB, int NT>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_args a, int KT, int NTT) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [SK_WAVES][NT*MB*4][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int nt0 = blockIdx.x * NT;
+
+    const bf16_t* xrow[MB];
+    bool xvalid[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        int m = mb * 16 + r;
+        xvalid[mb] = m < a.M;
+        int64_t row = xvalid[mb] ? (a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m) : 0;
+        xrow[mb] = a.x + row * a.ldx;
+    }
+    f32x4 acc[NT][MB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int kt_per = (KT + SK_WAVES - 1) / SK_WAVES;
+    const int kt_begin = wave * kt_per;
+    const int kt_end = min(KT, kt_begin + kt_per);
+    const bf16_t* wbase[NT];
+    bool tvalid[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        tvalid[t] = (nt0 + t) < NTT;
+        wbase[t] = a.wp + ((int64_t)(tvalid[t] ? nt0 + t : 0) * KT) * 512 + lane * 8;
+    }
+#pragma unroll 4
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int k = kt * 32 + g * 8;
+        bf16x8 wf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wbase[t] + (int64_t)kt * 512));
+        bf16x8 xf[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) xf[mb] = (xvalid[mb] && k < a.K) ? ldg_frag(xrow[mb] + k) : zero_frag();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(wf[t], xf[mb], acc[t][mb]);
+    }
+    // cross-wave reduction through LDS
+    constexpr int E4 = NT * MB;  // f32x4 fragments per lane
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            f32x4* dst = reinterpret_cast<f32x4*>(red) + ((wave * E4 + t * MB + mb) * 64 + lane);
+            *dst = acc[t][mb];
+        }
+    __syncthreads();
+    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    if (a.epilogue & UMV_EPI_SWIGLU) {
+        // tiles come in (gate, up) pairs; NT is even
+        for (int idx = tid; idx < (NT / 2) * MB * 64; idx += SK_WAVES * 64) {
+            int l = idx & 63;
+            int f = idx >> 6;  // pair*MB + mb
+            int pair = f / MB, mb = f % MB;
+            f32x4 sg = {0, 0, 0, 0}, su = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) {
+                sg += reinterpret_cast<f32x4*>(red)[(w * E4 + (2 * pair) * MB + mb) * 64 + l];
+                su += reinterpret_cast<f32x4*>(red)[(w * E4 + (2 * pair + 1) * MB + mb) * 64 + l];
+            }
+            int m = mb * 16 + (l & 15);
+            int ntile = nt0 + 2 * pair;
+            if (m < a.M && ntile < NTT) {
+                int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+                int c0 = (ntile >> 1) * 16 + (l >> 4) * 4;
+                float gg[4] = {sg.x, sg.y, sg.z, sg.w}, uu[4] = {su.x, su.y, su.z, su.w};
+                epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < E4 * 64; idx += SK_WAVES * 64) {
+            int l = idx & 63;
+            int f = idx >> 6;  // t*MB + mb
+            int t = f / MB, mb = f % MB;
+            f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) s += reinterpret_cast<f32x4*>(red)[(w * E4 + f) * 64 + l];
+            int m = mb * 16 + (l & 15);
+            int n0 = (nt0 + t) * 16 + (l >> 4) * 4;
+            if (m < a.M && n0 < a.N) {
+                int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+                epi_store4(e, orow, n0, s.x, s.y, s.z, s.w);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- tiled (M > 64)
+// Workgroup tile 128(n) x 128(m), 4 waves as 2(n) x 2(m), wave tile 64 x 64 = 4x4 MFMA tiles.
+// x tile (128 rows x 32 k) is staged through LDS in B-fragment order so each wave's four
+// x fragments are conflict-free 16-byte reads shared by the two waves of an m-half; W
+// fragments stream from the packed image (1 KiB contiguous per wave instruction).
+#define TG_BM 128
+#define TG_BN 128
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[2][TG_BM / 16][64][8];  // [buf][m-tile][lane][8] = 2 x 8 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+    // m-blocks fastest so that co-running workgroups share one W panel in L2
+    const int mblk = blockIdx.x % mblocks;
+    const int nblk = blockIdx.x / mblocks;
+    const int m0 = mblk * TG_BM;
+    const int nt_base = nblk * (TG_BN / 16) + wn * 4;
+
+    // staging role: thread -> (m-tile, lane) pairs; 8 m-tiles x 64 lanes = 512 fragments, 2 per thread
+    const bf16_t* srow[2];
+    bool svalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = tid + i * 256;      // 0..511
+        int mt = f >> 6, l = f & 63;
+        int m = m0 + mt * 16 + (l & 15);
+        svalid[i] = m < a.M;
+        int64_t row = svalid[i] ? (a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m) : 0;
+        srow[i] = a.x + row * a.ldx + (l >> 4) * 8;
+    }
+    const bf16_t* wbase[4];
+    bool tvalid[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        tvalid[t] = (nt_base + t) < NTT;
+        wbase[t] = a.wp + ((int64_t)(tvalid[t] ? nt_base + t : 0) * KT) * 512 + lane * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: stage k-tile 0
+    bf16x8 stage[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int k = (( (tid + i * 256) & 63) >> 4) * 8;
+        stage[i] = (svalid[i] && k < a.K) ? ldg_frag(srow[i]) : zero_frag();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = tid + i * 256;
+        *reinterpret_cast<bf16x8*>(&xs[0][f >> 6][f & 63][0]) = stage[i];
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        // issue next x tile loads (registers) and this tile's W fragment loads early
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int k = (kt + 1) * 32 + (((tid + i * 256) & 63) >> 4) * 8;
+                stage[i] = (svalid[i] && k < a.K) ? ldg_frag(srow[i] + (int64_t)(kt + 1) * 32) : zero_frag();
+            }
+        }
+        bf16x8 wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = ldg_frag(wbase[t] + (int64_t)kt * 512);
+        bf16x8 xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(&xs[cur][wm * 4 + j][lane][0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int f = tid + i * 256;
+                *reinterpret_cast<bf16x8*>(&xs[cur ^ 1][f >> 6][f & 63][0]) = stage[i];
+            }
+        }
+        __syncthreads();
+    }
+    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + (wm * 4 + j) * 16 + r;
+        if (m >= a.M) continue;
+        int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+        if (a.epilogue & UMV_EPI_SWIGLU) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                int ntile = nt_base + 2 * p;
+                if (ntile >= NTT) continue;
+                int c0 = (ntile >> 1) * 16 + g * 4;
+                float gg[4] = {acc[2 * p][j].x, acc[2 * p][j].y, acc[2 * p][j].z, acc[2 * p][j].w};
+                float uu[4] = {acc[2 * p + 1][j].x, acc[2 * p + 1][j].y, acc[2 * p + 1][j].z, acc[2 * p + 1][j].w};
+                epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int n0 = (nt_base + t) * 16 + g * 4;
+                if (n0 >= a.N) continue;
+                epi_store4(e, orow, n0, acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w);
+            }
+        }
+    }
+}
+
+template <int MB, int NT>
+static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
+    int blocks = (NTT + NT - 1) / NT;
+    size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT, NTT);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
+    UMV_CHECK(ap != nullptr, UMV_ERR_ARG, "gemm: null args");
+    umv_gemm_args a = *ap;
+    UMV_CHECK(a.x && a.wp && a.out, UMV_ERR_ARG, "gemm: null pointer");
+    UMV_CHECK(a.M >= 0 && a.N > 0 && a.K > 0, UMV_ERR_ARG, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    UMV_CHECK((a.K % 8) == 0 && (a.ldx % 8) == 0, UMV_ERR_ARG, "gemm: K (%d) and ldx (%lld) must be multiples of 8", a.K,
+              (long long)a.ldx);
+    UMV_CHECK(!(a.epilogue & UMV_EPI_BIAS) || a.bias, UMV_ERR_ARG, "gemm: BIAS without bias pointer");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_RESIDUAL) || a.residual, UMV_ERR_ARG, "gemm: RESIDUAL without residual pointer");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm: SWIGLU needs N %% 32 == 0");
+    if (a.M == 0) return UMV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int KT = (a.K + 31) / 32;
+    const int NTT = (a.N + 15) / 16;
+    if (a.M <= 64) {
+        const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
+        if (a.M <= 16) return two ? launch_skinny<1, 2>(a, KT, NTT, s) : launch_skinny<1, 1>(a, KT, NTT, s);
+        if (a.M <= 32) return two ? launch_skinny<2, 2>(a, KT, NTT, s) : launch_skinny<2, 1>(a, KT, NTT, s);
+        return two ? launch_skinny<4, 2>(a, KT, NTT, s) : launch_skinny<4, 1>(a, KT, NTT, s);
+    }
+    int mblocks = (a.M + TG_BM - 1) / TG_BM;
+    int nblocks = (a.N + TG_BN - 1) / TG_BN;
+    hipLaunchKernelGGL(gemm_tiled_kernel, dim3(mblocks * nblocks), dim3(256), 0, s, a, KT, NTT, mblocks);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}

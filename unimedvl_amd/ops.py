@@ -1,0 +1,210 @@
+"""Thin torch-tensor wrappers over the C ABI (torch is used for device memory and
+streams only).  Every function launches a hand-written gfx950 kernel from
+libunimedvl_hip.so on torch's current stream; there is no fallback path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_GELU_TANH, EPI_OUT_F32, EPI_RESIDUAL, EPI_SILU, EPI_SWIGLU, AttnArgs, GemmArgs,
+                   QkvPostArgs, check)
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.UmvError(f"{name}: tensor must live on the GPU (no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.UmvError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+class PackedLinear:
+    """nn.Linear weight [N,K] (+bias) re-tiled for the MFMA GEMM kernels."""
+
+    __slots__ = ("wp", "bias", "N", "K", "swiglu")
+
+    def __init__(self, wp, bias, N, K, swiglu=False):
+        self.wp, self.bias, self.N, self.K, self.swiglu = wp, bias, N, K, swiglu
+
+    @staticmethod
+    def from_weight(w, bias=None):
+        lib = _lib.load()
+        w = _req(w.contiguous(), BF16, "weight")
+        N, K = w.shape
+        wp = torch.empty(lib.umv_packed_weight_elems(N, K), dtype=BF16, device=w.device)
+        check(lib.umv_pack_weight_bf16(_p(w), _p(wp), N, K, _stream()), "umv_pack_weight_bf16")
+        return PackedLinear(wp, None if bias is None else bias.contiguous(), N, K)
+
+    @staticmethod
+    def from_gate_up(gate, up):
+        lib = _lib.load()
+        gate = _req(gate.contiguous(), BF16, "gate")
+        up = _req(up.contiguous(), BF16, "up")
+        I, K = gate.shape
+        assert I % 16 == 0, "intermediate size must be a multiple of 16"
+        wp = torch.empty(lib.umv_packed_weight_elems(2 * I, K), dtype=BF16, device=gate.device)
+        check(lib.umv_pack_weight_swiglu_bf16(_p(gate), _p(up), _p(wp), I, K, _stream()), "umv_pack_weight_swiglu_bf16")
+        return PackedLinear(wp, None, 2 * I, K, swiglu=True)
+
+    def nbytes(self):
+        return self.wp.numel() * 2
+
+
+def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True):
+    """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}."""
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    assert x.stride(-1) == 1
+    M = x.shape[0] if M is None else M
+    flags = 0
+    if lin.bias is not None and use_bias:
+        flags |= EPI_BIAS
+    if act == "gelu_tanh":
+        flags |= EPI_GELU_TANH
+    elif act == "silu":
+        flags |= EPI_SILU
+    elif act is not None:
+        raise ValueError(act)
+    if lin.swiglu:
+        flags |= EPI_SWIGLU
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+    if out_f32:
+        flags |= EPI_OUT_F32
+    n_out = lin.N // 2 if lin.swiglu else lin.N
+    rows_out = x.shape[0] if row_idx is None else None
+    if out is None:
+        assert row_idx is None, "row-indexed GEMM writes into a caller-provided buffer"
+        out = torch.empty((rows_out, n_out), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    a = GemmArgs(
+        x=x.data_ptr(), ldx=x.stride(0), wp=lin.wp.data_ptr(),
+        bias=lin.bias.data_ptr() if (flags & EPI_BIAS) else None,
+        residual=residual.data_ptr() if residual is not None else None,
+        ldr=residual.stride(0) if residual is not None else 0,
+        out=out.data_ptr(), ldo=out.stride(0),
+        row_idx=row_idx.data_ptr() if row_idx is not None else None,
+        M=M, N=lin.N, K=lin.K, epilogue=flags)
+    check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
+    return out
+
+
+def rmsnorm(x, w, eps, out=None, w_gen=None, expert=None):
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    T, H = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(lib.umv_rmsnorm_bf16(_p(x), _p(w), _p(w_gen), _p(expert), _p(out), T, H, eps, _stream()), "umv_rmsnorm_bf16")
+    return out
+
+
+def layernorm(x, w, b, eps, out=None):
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    T, H = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(lib.umv_layernorm_bf16(_p(x), _p(w), _p(b), _p(out), T, H, eps, _stream()), "umv_layernorm_bf16")
+    return out
+
+
+def embed_gather(table, ids, out=None, out_rows=None):
+    lib = _lib.load()
+    _req(table, BF16, "table")
+    _req(ids, torch.int64, "ids")
+    T, H = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((T, H), dtype=BF16, device=table.device)
+    check(lib.umv_embed_gather_bf16(_p(table), _p(ids), _p(out_rows), _p(out), T, H, _stream()), "umv_embed_gather_bf16")
+    return out
+
+
+def add_rows(a, out, bcast=None, table=None, idx=None, out_rows=None):
+    lib = _lib.load()
+    _req(a, BF16, "a")
+    T, H = a.shape
+    check(lib.umv_add_rows_bf16(_p(a), _p(bcast), _p(table), _p(idx), _p(out_rows), _p(out), T, H, _stream()),
+          "umv_add_rows_bf16")
+    return out
+
+
+def argmax(logits, out=None):
+    lib = _lib.load()
+    _req(logits, BF16, "logits")
+    M, V = logits.shape
+    out = torch.empty((M,), dtype=torch.int64, device=logits.device) if out is None else out
+    check(lib.umv_argmax_bf16(_p(logits), logits.stride(0), _p(out), M, V, _stream()), "umv_argmax_bf16")
+    return out
+
+
+def cast_pad(x, Kp):
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    T, K = x.shape
+    out = torch.empty((T, Kp), dtype=BF16, device=x.device)
+    check(lib.umv_cast_pad_f32_bf16(_p(x), x.stride(0), _p(out), Kp, T, K, Kp, _stream()), "umv_cast_pad_f32_bf16")
+    return out
+
+
+class KVSlab:
+    """One layer's K / V^T slabs: K [seg][nkv][cap][hd], V^T [seg][nkv][hd][cap]."""
+
+    __slots__ = ("k", "vt", "nseg", "nkv", "cap", "hd")
+
+    def __init__(self, nseg, nkv, cap, hd, device):
+        assert cap % 32 == 0
+        self.k = torch.zeros((nseg, nkv, cap, hd), dtype=BF16, device=device)
+        self.vt = torch.zeros((nseg, nkv, hd, cap), dtype=BF16, device=device)
+        self.nseg, self.nkv, self.cap, self.hd = nseg, nkv, cap, hd
+
+    def strides(self):
+        return dict(k_seg_stride=self.nkv * self.cap * self.hd, k_head_stride=self.cap * self.hd,
+                    v_seg_stride=self.nkv * self.hd * self.cap, v_head_stride=self.hd * self.cap, v_d_stride=self.cap)
+
+
+def qkv_post(qkv, q_out, slab, tok_seg, tok_slot, tok_pos, nq, nkv, hd, eps=1e-6, q_norm=None, k_norm=None,
+             q_norm_gen=None, k_norm_gen=None, expert=None, cos_tab=None, sin_tab=None, T=None, fp32_chain=False):
+    lib = _lib.load()
+    _req(qkv, BF16, "qkv")
+    T = qkv.shape[0] if T is None else T
+    a = QkvPostArgs(
+        qkv=qkv.data_ptr(), q_out=q_out.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(),
+        tok_seg=tok_seg.data_ptr(), tok_slot=tok_slot.data_ptr(),
+        tok_pos=None if tok_pos is None else tok_pos.data_ptr(),
+        expert=None if expert is None else expert.data_ptr(),
+        q_norm_w=None if q_norm is None else q_norm.data_ptr(), k_norm_w=None if k_norm is None else k_norm.data_ptr(),
+        q_norm_w_gen=None if q_norm_gen is None else q_norm_gen.data_ptr(),
+        k_norm_w_gen=None if k_norm_gen is None else k_norm_gen.data_ptr(),
+        cos_tab=None if cos_tab is None else cos_tab.data_ptr(), sin_tab=None if sin_tab is None else sin_tab.data_ptr(),
+        T=T, nq=nq, nkv=nkv, hd=hd, eps=eps, fp32_chain=int(fp32_chain), **slab.strides())
+    check(lib.umv_qkv_post(C.byref(a), _stream()), "umv_qkv_post")
+
+
+def attn_workspace(nseg, nq, hd, max_q, nsplit, device):
+    n = _lib.load().umv_attn_workspace_bytes(nseg, nq, hd, max_q, nsplit)
+    return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
+
+
+def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None):
+    lib = _lib.load()
+    _req(q, BF16, "q")
+    a = AttnArgs(
+        q=q.data_ptr(), out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
+        k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
+        causal=int(bool(causal)), max_q=max_q, max_kv=max_kv, nsplit=nsplit,
+        workspace=None if workspace is None else workspace.data_ptr(), **slab.strides())
+    check(lib.umv_attn_varlen(C.byref(a), _stream()), "umv_attn_varlen")
+    return out
+
+
+def decode_advance(tok_slot, tok_pos, kv_len):
+    lib = _lib.load()
+    check(lib.umv_decode_advance(_p(tok_slot), _p(tok_pos), _p(kv_len), tok_slot.numel(), _stream()), "umv_decode_advance")
