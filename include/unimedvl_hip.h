@@ -149,6 +149,15 @@ int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);
  * slot[b]+=1, pos[b]+=1, kv_len[b]+=1 (the .tolist() bookkeeping of bagel.py:1266-1275,1303-1310) */
 int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int B, umv_stream_t stream);
 
+/* ------------------------------------------------------------------ image head
+ * CFG combine + renorm + Euler update (bagel.py:1173-1207, :983), bf16 rounding after each
+ * op as the reference's bf16 tensors imply; x_t [N,D] fp32 updated in place.  v_* are
+ * [T, D] bf16 (row stride ldv); rows[n] picks the latent rows; seg_off [nseg+1] delimits the
+ * samples in n (norms are per sample).  renorm_type 0 global, 1 channel, 2 text_channel. */
+int umv_cfg_renorm_euler(float* x_t, const uint16_t* v_t, const uint16_t* v_text, const uint16_t* v_img, int64_t ldv,
+                         const int32_t* rows, const int32_t* seg_off, int nseg, float cfg_text_scale,
+                         float cfg_img_scale, float renorm_min, int renorm_type, float dt, int D, umv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,481 @@
+"""Host-side unified model: the reference's ``Bagel`` inference interface
+(codes/modeling/unimedvl/bagel.py:377-1392) over the MI355X engine.
+
+Same method names, argument names and return conventions as the reference, so that
+``InterleaveInferencer`` / ``chat``-style callers are drop-ins:
+    prepare_prompts / forward_cache_update_text        bagel.py:377 / :412
+    prepare_vit_images / forward_cache_update_vit      bagel.py:460 / :523
+    prepare_vae_images / forward_cache_update_vae      bagel.py:617 / :697
+    prepare_vae_latent / prepare_vae_latent_cfg        bagel.py:809 / :867
+    generate_image / _forward_flow                     bagel.py:901 / :989
+    prepare_start_tokens / generate_text / chat        bagel.py:1213 / :1236 / :1321
+The prepare_* functions build the same packed index tensors on the host (they are the
+boundary's data format); the forward_* functions consume what they need of them and
+run everything else on the GPU through libunimedvl_hip.so.
+"""
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .config import UniMedVLConfig
+from .data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
+from .decode import DecodeSession
+from .kvcache import NaiveCache
+from .llm import Qwen2MoT
+from .vit import SiglipVisionModel
+from .weights import GlueWeights, LLMWeights, ViTWeights
+
+BF16 = torch.bfloat16
+
+
+class Bagel:
+    def __init__(self, cfg: UniMedVLConfig, get, device="cuda", visual_gen=True, visual_und=True,
+                 interpolate_pos=False):
+        """`get(name)` returns reference-named tensors (see weights.py / shapes.py)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("unimedvl_amd needs an MI355X (ROCm) device; there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.language_model = Qwen2MoT(cfg, LLMWeights(cfg, get, self.device, load_gen=visual_gen), self.device)
+        self.glue = GlueWeights(cfg, get, self.device, visual_gen, visual_und)
+        self.vit_model = SiglipVisionModel(cfg, ViTWeights(cfg, get, self.device), self.device) if visual_und else None
+        self.vae_model = None
+        self.hidden_size = cfg.hidden
+        self.use_moe = True
+        self.num_heads = cfg.heads
+        self.latent_patch_size = cfg.latent_patch
+        self.latent_downsample = cfg.latent_downsample
+        self.max_latent_size = cfg.max_latent
+        self.latent_channel = cfg.z_channels
+        self.patch_latent_dim = cfg.latent_patch ** 2 * cfg.z_channels
+        self.vit_patch_size = cfg.patch
+        self.vit_max_num_patch_per_side = cfg.vit_side
+        self.vit_hidden_size = cfg.vit_hidden
+        self.get_flattened_position_ids = (get_flattened_position_ids_interpolate if interpolate_pos
+                                           else get_flattened_position_ids_extrapolate)
+        self.config = SimpleNamespace(
+            llm_config=SimpleNamespace(num_hidden_layers=cfg.layers, hidden_size=cfg.hidden,
+                                       num_attention_heads=cfg.heads, layer_module="Qwen2MoTDecoderLayer"),
+            visual_gen=visual_gen, visual_und=visual_und, latent_patch_size=cfg.latent_patch,
+            max_latent_size=cfg.max_latent, vit_max_num_patch_per_side=cfg.vit_side)
+        self.decode_use_graph = True
+        self.eos_check_every = 16
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ text
+    def prepare_prompts(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
+        text_ids, pos_ids, lens, text_idx, kv_idx = [], [], [], [], []
+        curr = 0
+        newlens, new_rope = [], []
+        for prompt, kvlen, rope in zip(prompts, curr_kvlens, curr_rope):
+            kv_idx.extend(range(curr, curr + kvlen))
+            curr += kvlen
+            ids = [new_token_ids["bos_token_id"]] + list(tokenizer.encode(prompt)) + [new_token_ids["eos_token_id"]]
+            lens.append(len(ids))
+            text_ids.extend(ids)
+            pos_ids.extend(range(rope, rope + len(ids)))
+            text_idx.extend(range(curr, curr + len(ids)))
+            newlens.append(kvlen + len(ids))
+            new_rope.append(rope + len(ids))
+            curr += len(ids)
+        generation_input = {
+            "text_token_lens": torch.tensor(lens, dtype=torch.int),
+            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+            "packed_text_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
+            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+        }
+        return generation_input, newlens, new_rope
+
+    @torch.no_grad()
+    def forward_cache_update_text(self, past_key_values: NaiveCache, packed_text_ids, packed_text_position_ids,
+                                  text_token_lens, packed_text_indexes=None, packed_key_value_indexes=None,
+                                  key_values_lens=None):
+        emb = self.language_model.embed_tokens(packed_text_ids)
+        out = self.language_model.forward_inference(
+            packed_query_sequence=emb, query_lens=text_token_lens, packed_query_position_ids=packed_text_position_ids,
+            packed_query_indexes=packed_text_indexes, past_key_values=past_key_values,
+            packed_key_value_indexes=packed_key_value_indexes, key_values_lens=key_values_lens,
+            update_past_key_values=True, is_causal=True, mode="und")
+        return out.past_key_values
+
+    # ------------------------------------------------------------------ ViT images
+    def prepare_vit_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
+        vit_idx, vit_lens, vit_tokens, vit_pos = [], [], [], []
+        text_ids, text_idx = [], []
+        seqlens, pos_ids, indexes, kv_idx = [], [], [], []
+        _curr = curr = 0
+        newlens, new_rope = [], []
+        for image, kvlen, rope in zip(images, curr_kvlens, curr_rope):
+            kv_idx.extend(range(curr, curr + kvlen))
+            curr += kvlen
+            text_ids.append(new_token_ids["start_of_image"])
+            text_idx.append(_curr)
+            indexes.append(curr)
+            curr += 1
+            _curr += 1
+            image_tensor = transforms(image)
+            vit_pos.append(self.get_flattened_position_ids(image_tensor.size(1), image_tensor.size(2), self.vit_patch_size,
+                                                           max_num_patches_per_side=self.vit_max_num_patch_per_side))
+            toks = patchify(image_tensor, self.vit_patch_size)
+            vit_tokens.append(toks)
+            n = toks.shape[0]
+            vit_lens.append(n)
+            vit_idx.extend(range(_curr, _curr + n))
+            indexes.extend(range(curr, curr + n))
+            curr += n
+            _curr += n
+            text_ids.append(new_token_ids["end_of_image"])
+            text_idx.append(_curr)
+            indexes.append(curr)
+            curr += 1
+            _curr += 1
+            pos_ids.extend([rope] * (n + 2))
+            seqlens.append(n + 2)
+            newlens.append(kvlen + n + 2)
+            new_rope.append(rope + 1)
+        generation_input = {
+            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+            "vit_token_seqlens": torch.tensor(vit_lens, dtype=torch.int),
+            "packed_vit_tokens": torch.cat(vit_tokens, dim=0),
+            "packed_vit_position_ids": torch.cat(vit_pos, dim=0),
+            "packed_vit_token_indexes": torch.tensor(vit_idx, dtype=torch.long),
+            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
+            "packed_indexes": torch.tensor(indexes, dtype=torch.long),
+            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
+            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+        }
+        return generation_input, newlens, new_rope
+
+    def encode_vit(self, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens):
+        """ViT tower + connector + vit_pos_embed (bagel.py:581-592); returns [N, hidden] bf16 (pre-scatter)."""
+        lens = vit_token_seqlens.to("cpu")
+        cu = torch.nn.functional.pad(torch.cumsum(lens, dim=0), (1, 0)).to(torch.int32)
+        vit = self.vit_model(packed_pixel_values=packed_vit_tokens, packed_flattened_position_ids=packed_vit_position_ids,
+                             cu_seqlens=cu, max_seqlen=int(lens.max()))
+        h = ops.gemm(vit, self.glue.conn1, act="gelu_tanh")
+        return ops.gemm(h, self.glue.conn2)
+
+    @torch.no_grad()
+    def forward_cache_update_vit(self, past_key_values: NaiveCache, packed_text_ids, packed_text_indexes,
+                                 packed_vit_tokens, packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens,
+                                 packed_position_ids, packed_seqlens, packed_indexes=None, packed_key_value_indexes=None,
+                                 key_values_lens=None):
+        dev = self.device
+        T = int(packed_seqlens.sum())
+        seq = torch.zeros((T, self.hidden_size), dtype=BF16, device=dev)
+        self.language_model.embed_tokens(packed_text_ids, out=seq,
+                                         out_rows=packed_text_indexes.to(device=dev, dtype=torch.int32))
+        conn = self.encode_vit(packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens)
+        ops.add_rows(conn, seq, table=self.glue.vit_pos, idx=packed_vit_position_ids.to(device=dev, dtype=torch.int64),
+                     out_rows=packed_vit_token_indexes.to(device=dev, dtype=torch.int32))
+        out = self.language_model.forward_inference(
+            packed_query_sequence=seq, query_lens=packed_seqlens, packed_query_position_ids=packed_position_ids,
+            packed_query_indexes=packed_indexes, past_key_values=past_key_values,
+            packed_key_value_indexes=packed_key_value_indexes, key_values_lens=key_values_lens,
+            update_past_key_values=True, is_causal=False, mode="und")
+        return out.past_key_values
+
+    # ------------------------------------------------------------------ VAE-encoded images (edit / reconstruction)
+    def prepare_vae_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids, timestep=0):
+        shapes, vae_pos, vae_idx = [], [], []
+        text_ids, text_idx = [], []
+        seqlens, pos_ids, indexes, kv_idx = [], [], [], []
+        _curr = curr = 0
+        tensors = []
+        newlens, new_rope = [], []
+        for image, kvlen, rope in zip(images, curr_kvlens, curr_rope):
+            kv_idx.extend(range(curr, curr + kvlen))
+            curr += kvlen
+            text_ids.append(new_token_ids["start_of_image"])
+            text_idx.append(_curr)
+            indexes.append(curr)
+            curr += 1
+            _curr += 1
+            image_tensor = transforms(image)
+            tensors.append(image_tensor)
+            vae_pos.append(self.get_flattened_position_ids(image_tensor.size(1), image_tensor.size(2),
+                                                           self.latent_downsample,
+                                                           max_num_patches_per_side=self.max_latent_size))
+            H, W = image_tensor.shape[1:]
+            h, w = H // self.latent_downsample, W // self.latent_downsample
+            shapes.append((h, w))
+            n = h * w
+            vae_idx.extend(range(_curr, _curr + n))
+            indexes.extend(range(curr, curr + n))
+            curr += n
+            _curr += n
+            text_ids.append(new_token_ids["end_of_image"])
+            text_idx.append(_curr)
+            indexes.append(curr)
+            curr += 1
+            _curr += 1
+            pos_ids.extend([rope] * (n + 2))
+            seqlens.append(n + 2)
+            newlens.append(kvlen + n + 2)
+            new_rope.append(rope + 1)
+        sizes = [t.shape for t in tensors]
+        max_size = [max(s) for s in zip(*sizes)]
+        padded = torch.zeros(size=(len(tensors), *max_size))
+        for i, t in enumerate(tensors):
+            padded[i, :, :t.shape[1], :t.shape[2]] = t
+        generation_input = {
+            "padded_images": padded,
+            "patchified_vae_latent_shapes": shapes,
+            "packed_vae_position_ids": torch.cat(vae_pos, dim=0),
+            "packed_timesteps": torch.tensor([timestep]),
+            "packed_vae_token_indexes": torch.tensor(vae_idx, dtype=torch.long),
+            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
+            "packed_indexes": torch.tensor(indexes, dtype=torch.long),
+            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
+            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+        }
+        return generation_input, newlens, new_rope
+
+    def time_embed(self, t_values):
+        """TimestepEmbedder (modeling_utils.py:87-109) for a vector of timesteps -> [n, hidden] bf16.
+        The 256-wide sinusoid is built on the host in fp32 with torch (same bits as the
+        reference); the two linears and the SiLU run on the GPU."""
+        import math
+        half = 128
+        t = torch.as_tensor(t_values, dtype=torch.float32).reshape(-1)
+        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+        args = t[:, None].float() * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(BF16).to(self.device)
+        h = ops.gemm(emb, self.glue.time0, act="silu")
+        return ops.gemm(h, self.glue.time2)
+
+    @torch.no_grad()
+    def forward_cache_update_vae(self, vae_model, past_key_values: NaiveCache, padded_images, patchified_vae_latent_shapes,
+                                 packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes, packed_text_ids,
+                                 packed_text_indexes, packed_position_ids, packed_seqlens, packed_indexes=None,
+                                 key_values_lens=None, packed_key_value_indexes=None, noise=None):
+        dev = self.device
+        T = int(packed_seqlens.sum())
+        seq = torch.zeros((T, self.hidden_size), dtype=BF16, device=dev)
+        text_rows = packed_text_indexes.to(device=dev, dtype=torch.int32)
+        vae_rows = packed_vae_token_indexes.to(device=dev, dtype=torch.int32)
+        self.language_model.embed_tokens(packed_text_ids, out=seq, out_rows=text_rows)
+        packed_latent = vae_model.encode_packed(padded_images, patchified_vae_latent_shapes, self.latent_patch_size,
+                                                noise=noise)                      # [sum h*w, p*p*c] bf16
+        t_emb = self.time_embed(packed_timesteps)                               # [1, hidden]
+        x = ops.gemm(packed_latent, self.glue.vae2llm)
+        ops.add_rows(x, seq, bcast=t_emb[0], table=self.glue.latent_pos,
+                     idx=packed_vae_position_ids.to(device=dev, dtype=torch.int64), out_rows=vae_rows)
+        out = self.language_model.forward_inference(
+            packed_query_sequence=seq, query_lens=packed_seqlens, packed_query_position_ids=packed_position_ids,
+            packed_query_indexes=packed_indexes, past_key_values=past_key_values, key_values_lens=key_values_lens,
+            packed_key_value_indexes=packed_key_value_indexes, update_past_key_values=True, is_causal=False, mode="gen",
+            packed_vae_token_indexes=packed_vae_token_indexes, packed_text_indexes=packed_text_indexes)
+        return out.past_key_values
+
+    # ------------------------------------------------------------------ image generation
+    def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
+        text_ids, text_idx = [], []
+        vae_pos, vae_idx, noises = [], [], []
+        pos_ids, seqlens, indexes, kv_idx = [], [], [], []
+        query_curr = curr = 0
+        for (H, W), kvlen, rope in zip(image_sizes, curr_kvlens, curr_rope):
+            kv_idx.extend(range(curr, curr + kvlen))
+            curr += kvlen
+            text_ids.append(new_token_ids["start_of_image"])
+            text_idx.append(query_curr)
+            indexes.append(curr)
+            curr += 1
+            query_curr += 1
+            vae_pos.append(self.get_flattened_position_ids(H, W, self.latent_downsample,
+                                                           max_num_patches_per_side=self.max_latent_size))
+            h, w = H // self.latent_downsample, W // self.latent_downsample
+            n = h * w
+            noises.append(torch.randn(n, self.latent_channel * self.latent_patch_size ** 2))   # CPU RNG, as the reference
+            vae_idx.extend(range(query_curr, query_curr + n))
+            indexes.extend(range(curr, curr + n))
+            curr += n
+            query_curr += n
+            text_ids.append(new_token_ids["end_of_image"])
+            text_idx.append(query_curr)
+            indexes.append(curr)
+            curr += 1
+            query_curr += 1
+            pos_ids.extend([rope] * (n + 2))
+            seqlens.append(n + 2)
+        return {
+            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
+            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
+            "packed_init_noises": torch.cat(noises, dim=0),
+            "packed_vae_position_ids": torch.cat(vae_pos, dim=0),
+            "packed_vae_token_indexes": torch.tensor(vae_idx, dtype=torch.long),
+            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
+            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+            "packed_indexes": torch.tensor(indexes, dtype=torch.long),
+            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
+        }
+
+    def prepare_vae_latent_cfg(self, curr_kvlens, curr_rope, image_sizes):
+        pos_ids, indexes, kv_idx = [], [], []
+        curr = 0
+        for (H, W), kvlen, rope in zip(image_sizes, curr_kvlens, curr_rope):
+            kv_idx.extend(range(curr, curr + kvlen))
+            curr += kvlen
+            n = (H // self.latent_downsample) * (W // self.latent_downsample)
+            indexes.extend(range(curr, curr + n + 2))
+            curr += n + 2
+            pos_ids.extend([rope] * (n + 2))
+        return {
+            "cfg_packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
+            "cfg_key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+            "cfg_packed_query_indexes": torch.tensor(indexes, dtype=torch.long),
+            "cfg_packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
+        }
+
+    @torch.no_grad()
+    def generate_image(self, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
+                       packed_vae_token_indexes, packed_seqlens, packed_position_ids, packed_indexes=None,
+                       past_key_values: NaiveCache = None, key_values_lens=None, packed_key_value_indexes=None,
+                       num_timesteps: int = 24, timestep_shift: float = 1.0, cfg_renorm_min: float = 0.0,
+                       cfg_renorm_type: str = "global", cfg_interval: Optional[Tuple[float, float]] = (0, 1),
+                       cfg_text_scale: float = 1.0, cfg_text_packed_query_indexes=None,
+                       cfg_text_packed_position_ids=None, cfg_text_past_key_values: Optional[NaiveCache] = None,
+                       cfg_text_key_values_lens=None, cfg_text_packed_key_value_indexes=None,
+                       cfg_img_scale: float = 1.0, cfg_img_packed_query_indexes=None, cfg_img_packed_position_ids=None,
+                       cfg_img_past_key_values: Optional[NaiveCache] = None, cfg_img_key_values_lens=None,
+                       cfg_img_packed_key_value_indexes=None, cfg_type: str = "parallel", callback=None):
+        """Rectified-flow Euler sampler with dual CFG + renorm (bagel.py:901-986, 989-1211)."""
+        if cfg_renorm_type not in ("global", "channel", "text_channel"):
+            raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
+        dev = self.device
+        lm, g = self.language_model, self.glue
+        x_t = packed_init_noises.to(device=dev, dtype=torch.float32).contiguous().clone()
+        N, D = x_t.shape
+        seqlens = [int(v) for v in packed_seqlens.tolist()]
+        T = sum(seqlens)
+        # schedule on the host in fp32, exactly as the reference builds it (bagel.py:937-940)
+        ts = torch.linspace(1, 0, num_timesteps)
+        ts = timestep_shift * ts / (1 + (timestep_shift - 1) * ts)
+        dts = ts[:-1] - ts[1:]
+        ts = ts[:-1]
+        t_emb_all = self.time_embed(ts)                           # rows identical within a step: compute once
+        text_rows = packed_text_indexes.to(device=dev, dtype=torch.int32)
+        vae_rows = packed_vae_token_indexes.to(device=dev, dtype=torch.int32)
+        vae_pos = packed_vae_position_ids.to(device=dev, dtype=torch.int64)
+        seq = torch.zeros((T, self.hidden_size), dtype=BF16, device=dev)
+        lm.embed_tokens(packed_text_ids, out=seq, out_rows=text_rows)
+        seg_off = [0]
+        for n in seqlens:
+            seg_off.append(seg_off[-1] + n - 2)
+        seg_off_d = torch.tensor(seg_off, dtype=torch.int32).to(dev)
+        common = dict(query_lens=packed_seqlens, update_past_key_values=False, is_causal=False, mode="gen",
+                      packed_vae_token_indexes=packed_vae_token_indexes, packed_text_indexes=packed_text_indexes)
+
+        def velocity(cache, pos_ids, kv_lens):
+            out = lm.forward_inference(packed_query_sequence=seq, packed_query_position_ids=pos_ids,
+                                       past_key_values=cache, key_values_lens=kv_lens, **common)
+            return ops.gemm(out.packed_query_sequence, g.llm2vae)          # [T, D]; vae rows picked by the CFG kernel
+
+        rtype = {"global": 0, "channel": 1, "text_channel": 2}[cfg_renorm_type]
+        for i in range(len(ts)):
+            t = float(ts[i])
+            if t > cfg_interval[0] and t <= cfg_interval[1]:
+                s_text, s_img = cfg_text_scale, cfg_img_scale
+            else:
+                s_text, s_img = 1.0, 1.0
+            xb = ops.cast_pad(x_t, D)
+            h = ops.gemm(xb, g.vae2llm)
+            ops.add_rows(h, seq, bcast=t_emb_all[i], table=g.latent_pos, idx=vae_pos, out_rows=vae_rows)
+            v_t = velocity(past_key_values, packed_position_ids, key_values_lens)
+            v_text = v_img = None
+            if s_text > 1.0:
+                v_text = velocity(cfg_text_past_key_values, cfg_text_packed_position_ids, cfg_text_key_values_lens)
+            if s_img > 1.0 and s_text > 1.0:   # the reference runs this pass but drops it when s_text <= 1 (bagel.py:1173,1208)
+                v_img = velocity(cfg_img_past_key_values, cfg_img_packed_position_ids, cfg_img_key_values_lens)
+            ops.cfg_renorm_euler(x_t, v_t, v_text, v_img, vae_rows, seg_off_d, len(seqlens), s_text, s_img,
+                                 cfg_renorm_min, rtype, float(dts[i]))
+            if callback is not None:
+                callback(i, x_t)
+        return x_t.split([n - 2 for n in seqlens])
+
+    # ------------------------------------------------------------------ text generation
+    def prepare_start_tokens(self, curr_kvlens, curr_rope, new_token_ids):
+        start, kv_idx, pos = [], [], []
+        curr = 0
+        for kvlen, rope in zip(curr_kvlens, curr_rope):
+            kv_idx.extend(range(curr, curr + kvlen))
+            start.append(new_token_ids["bos_token_id"])
+            pos.append(rope)
+            curr += kvlen
+        return {
+            "packed_start_tokens": torch.tensor(start, dtype=torch.long),
+            "packed_query_position_ids": torch.tensor(pos, dtype=torch.long),
+            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
+            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
+        }
+
+    @torch.no_grad()
+    def generate_text(self, past_key_values: NaiveCache, packed_key_value_indexes=None, key_values_lens=None,
+                      packed_start_tokens=None, packed_query_position_ids=None, max_length: int = 0,
+                      do_sample: bool = False, temperature: float = 1.0, end_token_id: int = None,
+                      return_logits: bool = False, per_sample_eos: bool = False):
+        """Greedy decode (bagel.py:1236-1317).  Returns [steps, B] int64 whose row 0 holds the
+        start tokens.  Like the reference, the batch stops when SAMPLE 0 emits end_token_id
+        (bagel.py:1313); per_sample_eos=True is the batched extension (stops when every sample
+        has emitted it; rows after a sample's EOS keep decoding and should be ignored)."""
+        if do_sample:
+            raise NotImplementedError("sampling (multinomial) is a 'next' row; greedy only")
+        if key_values_lens is not None and [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
+            raise ValueError("key_values_lens disagree with the cache")
+        sess = DecodeSession(self.language_model, past_key_values, packed_start_tokens, packed_query_position_ids,
+                             max_length, use_graph=self.decode_use_graph and not return_logits)
+        logits = []
+        steps = 0
+        stop = None
+        while steps < max_length:
+            n = 1 if return_logits else min(self.eos_check_every, max_length - steps)
+            sess.step(n)
+            if return_logits:
+                logits.append(sess.logits.clone())
+            steps += n
+            if end_token_id is not None:
+                pred = sess.pred_ids[:steps].cpu()
+                hit = pred == end_token_id
+                if per_sample_eos:
+                    if bool(hit.any(0).all()):
+                        stop = int(hit.float().argmax(0).max()) + 1
+                        break
+                elif bool(hit[:, 0].any()):
+                    stop = int(hit[:, 0].float().argmax()) + 1
+                    break
+        rows = stop if stop is not None else steps
+        sess.commit(rows)
+        out = sess.in_ids[:rows].clone()
+        if return_logits:
+            return out, torch.stack(logits[:rows], 0)
+        return out
+
+    # ------------------------------------------------------------------ convenience (evaluation path)
+    @torch.no_grad()
+    def chat(self, tokenizer, new_token_ids, image_transform, images, prompt, max_length: int,
+             do_sample: bool = False, temperature: float = 1.0):
+        """ViT-only VQA convenience path (bagel.py:1321-1392)."""
+        cache = NaiveCache(self.cfg.layers)
+        newlens, new_rope = [0], [0]
+        for image in images:
+            gi, newlens, new_rope = self.prepare_vit_images(newlens, new_rope, [image], image_transform, new_token_ids)
+            cache = self.forward_cache_update_vit(cache, **gi)
+        gi, newlens, new_rope = self.prepare_prompts(newlens, new_rope, [prompt], tokenizer, new_token_ids)
+        cache = self.forward_cache_update_text(cache, **gi)
+        gi = self.prepare_start_tokens(newlens, new_rope, new_token_ids)
+        ids = self.generate_text(past_key_values=cache, max_length=max_length, do_sample=do_sample,
+                                 temperature=temperature, end_token_id=new_token_ids["eos_token_id"], **gi)
+        output = tokenizer.decode(ids[:, 0])
+        return output.split("<|im_end|>")[0].split("<|im_start|>")[1]

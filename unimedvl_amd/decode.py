@@ -1,0 +1,112 @@
+"""Greedy KV-cache decode with all bookkeeping on the device.
+
+The reference loop (codes/modeling/unimedvl/bagel.py:1262-1314) rebuilds its index
+tensors with .tolist() splits every step, re-merges the whole KV tensor in every layer
+and syncs with the host three times per token.  Here one decode step is a fixed kernel
+sequence over static buffers (embed -> 28 x [rmsnorm, QKV GEMM, q/k-norm+RoPE+KV append,
+split-KV attention, o_proj+residual, rmsnorm, SwiGLU GEMM, down+residual] -> norm ->
+lm_head -> argmax -> advance), captured once into a HIP graph and replayed; slot,
+position and kv_len counters live in device memory (umv_decode_advance).
+"""
+import torch
+
+from . import ops
+from .kvcache import NaiveCache
+
+BF16 = torch.bfloat16
+
+
+class DecodeSession:
+    def __init__(self, llm, cache: NaiveCache, start_tokens, positions, max_length, use_graph=True, nsplit=None):
+        cfg, dev = llm.cfg, llm.device
+        self.llm, self.cache, self.cfg, self.dev = llm, cache, cfg, dev
+        B = len(cache.lens)
+        self.B = B
+        self.max_length = max_length
+        nq, nkv, hd, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
+        cache.ensure(B, max(cache.lens) + max_length + 1, nkv, hd, dev)
+        self.lens0 = list(cache.lens)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.ids = start_tokens.to(device=dev, dtype=torch.int64).clone()
+        self.tok_seg = torch.arange(B, **i32)
+        self.tok_slot = torch.tensor(cache.lens, dtype=torch.int32).to(dev)
+        self.tok_pos = positions.to(device=dev, dtype=torch.int32).clone()
+        self.kv_len = self.tok_slot + 1
+        self.cu_q = torch.arange(B + 1, **i32)
+        self.in_ids = torch.zeros((max_length, B), dtype=torch.int64, device=dev)    # token fed at each step
+        self.pred_ids = torch.zeros((max_length, B), dtype=torch.int64, device=dev)  # token predicted at each step
+        self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        max_kv = max(cache.lens) + max_length + 1
+        self.nsplit = nsplit if nsplit is not None else (8 if max_kv >= 256 else 1)
+        self.ws = ops.attn_workspace(B, nq, hd, 1, self.nsplit, dev) if self.nsplit > 1 else None
+        self.max_kv = max_kv
+        # static activations
+        self.seq = torch.empty((B, H), dtype=BF16, device=dev)
+        self.x = torch.empty((B, H), dtype=BF16, device=dev)
+        self.qkv = torch.empty((B, (nq + 2 * nkv) * hd), dtype=BF16, device=dev)
+        self.q = torch.empty((B, nq, hd), dtype=BF16, device=dev)
+        self.o = torch.empty((B, nq * hd), dtype=BF16, device=dev)
+        self.act = torch.empty((B, cfg.inter), dtype=BF16, device=dev)
+        self.hn = torch.empty((B, H), dtype=BF16, device=dev)
+        self.logits = torch.empty((B, cfg.vocab), dtype=BF16, device=dev)
+        self.steps_done = 0
+        self.graph = None
+        if use_graph:
+            self._capture()
+
+    def _step(self):
+        cfg, w, c = self.cfg, self.llm.w, self.cache
+        nq, nkv, hd = cfg.heads, cfg.kv_heads, cfg.head_dim
+        self.in_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
+        ops.embed_gather(w.embed, self.ids, out=self.seq)
+        for l in range(cfg.layers):
+            lw = w.und[l]
+            ops.rmsnorm(self.seq, lw.in_norm, cfg.rms_eps, out=self.x)
+            ops.gemm(self.x, lw.qkv, out=self.qkv)
+            ops.qkv_post(self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
+                         cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin)
+            ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
+                          self.nsplit, self.ws)
+            ops.gemm(self.o, lw.o, out=self.seq, residual=self.seq)
+            ops.rmsnorm(self.seq, lw.post_norm, cfg.rms_eps, out=self.x)
+            ops.gemm(self.x, lw.gate_up, out=self.act)
+            ops.gemm(self.act, lw.down, out=self.seq, residual=self.seq)
+        ops.rmsnorm(self.seq, w.norm, cfg.rms_eps, out=self.hn)
+        ops.gemm(self.hn, w.lm_head, out=self.logits)
+        ops.argmax(self.logits, out=self.ids)
+        self.pred_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
+        ops.decode_advance(self.tok_slot, self.tok_pos, self.kv_len)
+        self.step_idx.add_(1)
+
+    def _capture(self):
+        # the captured step appends at slot = lens0 and bumps the counters; warm up on a side
+        # stream first (lazy module loading), then restore the counters so capture sees a clean state
+        saved = [t.clone() for t in (self.ids, self.tok_slot, self.tok_pos, self.kv_len, self.step_idx)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, v in zip((self.ids, self.tok_slot, self.tok_pos, self.kv_len, self.step_idx), saved):
+            t.copy_(v)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step()
+        # capture does not execute; counters are still at their initial values
+        self.graph = g
+
+    def step(self, n=1):
+        for _ in range(n):
+            if self.steps_done >= self.max_length:
+                raise RuntimeError("decode session exhausted")
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step()
+            self.steps_done += 1
+
+    def commit(self, steps=None):
+        """Make the cache's host-side lengths reflect `steps` decoded tokens."""
+        steps = self.steps_done if steps is None else steps
+        self.cache.lens = [l + steps for l in self.lens0]

@@ -1,0 +1,101 @@
+"""KV cache as in-place slabs.
+
+Drop-in for the reference's ``NaiveCache`` (codes/modeling/unimedvl/qwen2_navit.py:207-221):
+same constructor ``NaiveCache(num_layers)``, ``num_layers`` / ``seq_lens`` properties,
+and it survives ``copy.deepcopy`` (the inferencer snapshots contexts that way,
+codes/inferencer.py:587,600,607,261).  The reference re-allocates and re-scatters the
+whole ``[sum K, kvh, hd]`` tensor on every forward (qwen2_navit.py:585-600); here each
+layer owns  K [seg][kvh][cap][hd]  and  V^T [seg][kvh][hd][cap]  bf16 slabs that are
+appended in place, with the per-sample lengths kept on the host.
+"""
+import torch
+
+from . import ops
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class NaiveCache:
+    def __init__(self, num_layers):
+        self._num_layers = num_layers
+        self.slabs = None          # list[KVSlab] once materialised
+        self.lens = []             # committed tokens per segment (host ints)
+        self.nkv = self.hd = None
+        self.device = None
+
+    # --- reference-compatible surface
+    @property
+    def num_layers(self):
+        return self._num_layers
+
+    @property
+    def seq_lens(self):
+        return sum(self.lens)
+
+    @property
+    def key_cache(self):
+        """{layer: [sum K, kvh, hd]} view materialised on demand (tests / debugging)."""
+        return {l: self.packed_keys(l) for l in range(self._num_layers)}
+
+    @property
+    def value_cache(self):
+        return {l: self.packed_values(l) for l in range(self._num_layers)}
+
+    def packed_keys(self, layer):
+        if self.slabs is None or not any(self.lens):
+            return None
+        return torch.cat([self.slabs[layer].k[s, :, :n].transpose(0, 1) for s, n in enumerate(self.lens)], 0)
+
+    def packed_values(self, layer):
+        if self.slabs is None or not any(self.lens):
+            return None
+        return torch.cat([self.slabs[layer].vt[s, :, :, :n].permute(2, 0, 1) for s, n in enumerate(self.lens)], 0)
+
+    # --- slab management
+    @property
+    def cap(self):
+        return 0 if self.slabs is None else self.slabs[0].cap
+
+    def ensure(self, nseg, need_cap, nkv, hd, device):
+        """Make room for `need_cap` tokens per segment (committed + the call's new tokens)."""
+        need_cap = _round_up(max(need_cap, 32), 32)
+        if self.slabs is None:
+            cap = _round_up(max(need_cap, 256), 256)
+            self.slabs = [ops.KVSlab(nseg, nkv, cap, hd, device) for _ in range(self._num_layers)]
+            self.lens = [0] * nseg
+            self.nkv, self.hd, self.device = nkv, hd, device
+            return
+        if nseg != len(self.lens):
+            raise ValueError(f"cache holds {len(self.lens)} samples, call has {nseg}")
+        if need_cap > self.cap:
+            cap = _round_up(max(need_cap, 2 * self.cap), 256)
+            keep = max(self.lens)
+            new = []
+            for old in self.slabs:
+                s = ops.KVSlab(nseg, self.nkv, cap, self.hd, self.device)
+                if keep:
+                    s.k[:, :, :keep].copy_(old.k[:, :, :keep])
+                    s.vt[:, :, :, :keep].copy_(old.vt[:, :, :, :keep])
+                new.append(s)
+            self.slabs = new
+
+    def reserve(self, nseg, cap, nkv, hd, device):
+        """Pre-size (bench / serving) so that decode never re-allocates."""
+        self.ensure(nseg, cap, nkv, hd, device)
+
+    def __deepcopy__(self, memo):
+        c = NaiveCache(self._num_layers)
+        c.lens = list(self.lens)
+        c.nkv, c.hd, c.device = self.nkv, self.hd, self.device
+        if self.slabs is not None:
+            keep = _round_up(max(max(self.lens), 1), 32)
+            cap = self.cap
+            c.slabs = []
+            for old in self.slabs:
+                s = ops.KVSlab(len(self.lens), self.nkv, cap, self.hd, self.device)
+                s.k[:, :, :keep].copy_(old.k[:, :, :keep])
+                s.vt[:, :, :, :keep].copy_(old.vt[:, :, :, :keep])
+                c.slabs.append(s)
+        return c

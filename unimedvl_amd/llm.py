@@ -1,0 +1,140 @@
+"""Packed Qwen2-MoT forward on the HIP kernels.
+
+Mirrors ``Qwen2ForCausalLM.forward_inference`` / ``Qwen2Model.forward_inference`` /
+``Qwen2MoTDecoderLayer.forward_inference`` / ``PackedAttentionMoT.forward_inference``
+(codes/modeling/unimedvl/qwen2_navit.py:1243, 1115-1176, 843-902, 525-626): same
+arguments, same meaning.  Differences in mechanism, not in results:
+  * the KV cache is appended in place (kvcache.NaiveCache) instead of being re-merged
+    through packed_query_indexes / packed_key_value_indexes, which are therefore only
+    validated, not used;
+  * q/k/v projections are one fused GEMM, gate/up one SwiGLU GEMM, residual adds live in
+    GEMM epilogues, q/k-norm + RoPE + cache write are one kernel;
+  * MoT routing (mode="gen") runs each expert's GEMM over its row subset through a row
+    index list instead of gather / zeros_like / scatter passes.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+from .config import UniMedVLConfig
+from .kvcache import NaiveCache
+from .weights import LLMWeights
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class BaseNavitOutputWithPast:
+    packed_query_sequence: torch.Tensor = None
+    past_key_values: Optional[NaiveCache] = None
+
+
+def _host_list(x):
+    if isinstance(x, torch.Tensor):
+        return [int(v) for v in x.tolist()]
+    return [int(v) for v in x]
+
+
+class Qwen2MoT:
+    def __init__(self, cfg: UniMedVLConfig, weights: LLMWeights, device):
+        self.cfg = cfg
+        self.w = weights
+        self.device = device
+        self.decode_nsplit = 8
+
+    # ------------------------------------------------------------------ embeddings / head
+    def embed_tokens(self, ids, out=None, out_rows=None):
+        ids = ids.to(device=self.device, dtype=torch.int64)
+        return ops.embed_gather(self.w.embed, ids, out=out, out_rows=out_rows)
+
+    def lm_head(self, h):
+        return ops.gemm(h, self.w.lm_head)
+
+    # ------------------------------------------------------------------ forward
+    def forward_inference(self, packed_query_sequence, query_lens, packed_query_position_ids,
+                          packed_query_indexes=None, past_key_values: NaiveCache = None, key_values_lens=None,
+                          packed_key_value_indexes=None, update_past_key_values=True, is_causal=True, mode="und",
+                          packed_vae_token_indexes=None, packed_text_indexes=None) -> BaseNavitOutputWithPast:
+        cfg, w, dev = self.cfg, self.w, self.device
+        nq, nkv, hd, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
+        seq = packed_query_sequence
+        if seq.dtype != BF16:
+            seq = seq.to(BF16)
+        seq = seq.contiguous()
+        T = seq.shape[0]
+        qlens = _host_list(query_lens)
+        nseg = len(qlens)
+        assert sum(qlens) == T, "query_lens do not add up to the packed sequence"
+        cache = past_key_values if past_key_values is not None else NaiveCache(cfg.layers)
+        if cache.slabs is None:
+            cache.ensure(nseg, max(qlens), nkv, hd, dev)
+        if key_values_lens is not None:
+            kvl = _host_list(key_values_lens)
+            if kvl != list(cache.lens):
+                raise ValueError(f"key_values_lens {kvl} disagree with the cache ({cache.lens})")
+        cache.ensure(nseg, max(c + q for c, q in zip(cache.lens, qlens)), nkv, hd, dev)
+
+        # per-token bookkeeping (host -> one small upload)
+        seg, slot = [], []
+        for s, (c, q) in enumerate(zip(cache.lens, qlens)):
+            seg += [s] * q
+            slot += list(range(c, c + q))
+        meta = torch.tensor([seg, slot], dtype=torch.int32).to(dev, non_blocking=True)
+        tok_seg, tok_slot = meta[0], meta[1]
+        tok_pos = packed_query_position_ids.to(device=dev, dtype=torch.int32)
+        cu = [0]
+        for q in qlens:
+            cu.append(cu[-1] + q)
+        lens_after = [c + q for c, q in zip(cache.lens, qlens)]
+        cuk = torch.tensor([cu, lens_after + [0]], dtype=torch.int32).to(dev, non_blocking=True)
+        cu_q, kv_len = cuk[0], cuk[1][:nseg]
+        max_q, max_kv = max(qlens), max(lens_after)
+
+        gen = mode == "gen"
+        expert = text_rows = vae_rows = None
+        if gen:
+            assert packed_vae_token_indexes is not None and packed_text_indexes is not None
+            vae_rows = packed_vae_token_indexes.to(device=dev, dtype=torch.int32)
+            text_rows = packed_text_indexes.to(device=dev, dtype=torch.int32)
+            expert = torch.zeros(T, dtype=torch.int32, device=dev)
+            expert[vae_rows.long()] = 1
+            n_text, n_vae = text_rows.numel(), vae_rows.numel()
+
+        decode = max_q == 1 and not gen
+        nsplit = self.decode_nsplit if (decode and max_kv >= 256) else 1
+        ws = ops.attn_workspace(nseg, nq, hd, max_q, nsplit, dev) if nsplit > 1 else None
+
+        x = torch.empty_like(seq)
+        qkv = torch.empty((T, (nq + 2 * nkv) * hd), dtype=BF16, device=dev)
+        qbuf = torch.empty((T, nq, hd), dtype=BF16, device=dev)
+        obuf = torch.empty((T, nq * hd), dtype=BF16, device=dev)
+        act = torch.empty((T, cfg.inter), dtype=BF16, device=dev)
+        if seq.data_ptr() == packed_query_sequence.data_ptr():
+            seq = seq.clone()   # residual stream is updated in place; never clobber the caller's tensor
+
+        def routed(xin, und_lin, gen_lin, out, residual=None):
+            if not gen:
+                return ops.gemm(xin, und_lin, out=out, residual=residual)
+            ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual)
+            ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual)
+            return out
+
+        for l in range(cfg.layers):
+            lu = w.und[l]
+            lg = w.gen[l] if gen else None
+            ops.rmsnorm(seq, lu.in_norm, cfg.rms_eps, out=x, w_gen=lg.in_norm if gen else None, expert=expert)
+            routed(x, lu.qkv, lg.qkv if gen else None, qkv)
+            ops.qkv_post(qkv, qbuf, cache.slabs[l], tok_seg, tok_slot, tok_pos, nq, nkv, hd, cfg.rms_eps,
+                         lu.q_norm, lu.k_norm, lg.q_norm if gen else None, lg.k_norm if gen else None, expert,
+                         w.cos, w.sin, fp32_chain=gen)
+            ops.attention(qbuf, obuf, cache.slabs[l], cu_q, kv_len, nq, nkv, hd, is_causal, max_q, max_kv, nsplit, ws)
+            routed(obuf, lu.o, lg.o if gen else None, seq, residual=seq)
+            ops.rmsnorm(seq, lu.post_norm, cfg.rms_eps, out=x, w_gen=lg.post_norm if gen else None, expert=expert)
+            routed(x, lu.gate_up, lg.gate_up if gen else None, act)
+            routed(act, lu.down, lg.down if gen else None, seq, residual=seq)
+        out = ops.rmsnorm(seq, w.norm, cfg.rms_eps, w_gen=w.norm_gen if gen else None, expert=expert)
+        if update_past_key_values:
+            cache.lens = lens_after
+        return BaseNavitOutputWithPast(packed_query_sequence=out, past_key_values=cache)

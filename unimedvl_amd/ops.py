@@ -208,3 +208,12 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
 def decode_advance(tok_slot, tok_pos, kv_len):
     lib = _lib.load()
     check(lib.umv_decode_advance(_p(tok_slot), _p(tok_pos), _p(kv_len), tok_slot.numel(), _stream()), "umv_decode_advance")
+
+
+def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img, renorm_min, rtype, dt):
+    lib = _lib.load()
+    _req(x_t, torch.float32, "x_t")
+    _req(v_t, BF16, "v_t")
+    check(lib.umv_cfg_renorm_euler(_p(x_t), _p(v_t), _p(v_text), _p(v_img), v_t.stride(0), _p(rows), _p(seg_off), nseg,
+                                   float(s_text), float(s_img), float(renorm_min), int(rtype), float(dt), x_t.shape[1],
+                                   _stream()), "umv_cfg_renorm_euler")

@@ -1,0 +1,61 @@
+"""Packed variable-resolution SigLIP tower on the HIP kernels.
+
+Mirrors ``SiglipVisionModel.forward(packed_pixel_values, packed_flattened_position_ids,
+cu_seqlens, max_seqlen)`` (codes/modeling/unimedvl/siglip_navit.py:389-402, 345-371):
+linear patch embed + learned absolute positions, pre-LN blocks with one full-attention
+window per image (cu_seqlens), post-LN.  head_dim 72 runs on the same varlen attention
+kernel as the LLM (zero-padded to 96 / 80 inside MFMA fragments).
+"""
+import torch
+
+from . import ops
+from .config import UniMedVLConfig
+from .weights import ViTWeights
+
+BF16 = torch.bfloat16
+
+
+class SiglipVisionModel:
+    def __init__(self, cfg: UniMedVLConfig, weights: ViTWeights, device):
+        self.cfg, self.w, self.device = cfg, weights, device
+
+    def __call__(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
+        return self.forward(packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen)
+
+    def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
+        cfg, w, dev = self.cfg, self.w, self.device
+        nh, hd, h_dim = cfg.vit_heads, cfg.vit_head_dim, cfg.vit_hidden
+        px = packed_pixel_values.to(device=dev, dtype=torch.float32).contiguous()
+        N = px.shape[0]
+        pos_ids = packed_flattened_position_ids.to(device=dev, dtype=torch.int64)
+        cu_host = [int(v) for v in cu_seqlens.tolist()]
+        nimg = len(cu_host) - 1
+        lens = [cu_host[i + 1] - cu_host[i] for i in range(nimg)]
+        max_seqlen = int(max_seqlen)
+        cu_q = torch.tensor(cu_host, dtype=torch.int32).to(dev)
+        kv_len = torch.tensor(lens, dtype=torch.int32).to(dev)
+        seg, slot = [], []
+        for i, n in enumerate(lens):
+            seg += [i] * n
+            slot += list(range(n))
+        meta = torch.tensor([seg, slot], dtype=torch.int32).to(dev)
+
+        xb = ops.cast_pad(px, w.k_pad)                       # autocast's fp32->bf16 cast of the pixels
+        h = ops.gemm(xb, w.patch)                            # patch embedding (siglip_navit.py:190)
+        ops.add_rows(h, h, table=w.pos, idx=pos_ids)         # + position_embedding(ids) (:192)
+        slab = ops.KVSlab(nimg, nh, (max(lens) + 31) // 32 * 32, hd, dev)
+        x = torch.empty_like(h)
+        qkv = torch.empty((N, 3 * h_dim), dtype=BF16, device=dev)
+        q = torch.empty((N, nh, hd), dtype=BF16, device=dev)
+        o = torch.empty((N, h_dim), dtype=BF16, device=dev)
+        a = torch.empty((N, cfg.vit_inter), dtype=BF16, device=dev)
+        for lw in w.layers:
+            ops.layernorm(h, lw.ln1_w, lw.ln1_b, cfg.ln_eps, out=x)
+            ops.gemm(x, lw.qkv, out=qkv)
+            ops.qkv_post(qkv, q, slab, meta[0], meta[1], None, nh, nh, hd)
+            ops.attention(q, o, slab, cu_q, kv_len, nh, nh, hd, False, max_seqlen, max_seqlen)
+            ops.gemm(o, lw.out, out=h, residual=h)
+            ops.layernorm(h, lw.ln2_w, lw.ln2_b, cfg.ln_eps, out=x)
+            ops.gemm(x, lw.fc1, out=a, act="gelu_tanh")
+            ops.gemm(a, lw.fc2, out=h, residual=h)
+        return ops.layernorm(h, w.post_w, w.post_b, cfg.ln_eps)
