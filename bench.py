@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""UniMedVL-14B VQA greedy decode throughput on MI355X (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one greedy decode step of the whole hot path for a batch of 8 samples per GPU
+(embed -> 28 Qwen2-MoT layers over the in-place KV cache -> norm -> lm_head -> argmax), after
+a real ViT encode + LLM prefill of 8 synthetic 448x448 images and 32-token questions
+(context 1026 + 34 = 1060 tokens per sample).  Weights are random N(0, 0.02^2) bf16 at the
+full assumed 14B dims (no checkpoint, no network).  Data-parallel: every rank owns its own
+8 samples and a full weight replica; the only collective is one RCCL all-gather of the
+generated token ids.  One JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable by a copy kernel)
+
+
+def synth_image(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(1, 1, h // 32 + 2, w // 32 + 2, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False)[0]
+    img = (img / img.abs().max()).clamp(-1, 1)
+    return img.repeat(3, 1, 1).contiguous()
+
+
+class IdTokenizer:
+    def __init__(self, ids):
+        self.ids = ids
+
+    def encode(self, s):
+        return self.ids[int(s)]
+
+
+def cpu_baseline(batch, ctx, full_layers, seed=1234):
+    """Oracle (CPU restatement of the reference) timed on the host cores: full-width decode step,
+    2 of 28 layers + lm_head, scaled linearly to full depth.  Reported baseline, not a target."""
+    from oracle.unimedvl_cpu import OracleBagel, KVCache
+    from oracle.weights import FULL, llm_shapes
+    c = dict(FULL)
+    c["layers"] = 2
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in llm_shapes(c).items():
+        if "moe_gen" in k:
+            continue
+        if len(shp) == 1:
+            sd[k] = torch.ones(shp, dtype=torch.bfloat16)
+        else:
+            sd[k] = torch.empty(shp, dtype=torch.bfloat16).normal_(0, 0.02, generator=g)
+    o = OracleBagel(c, sd, None, attn_impl="sdpa")
+    hd, nkv = c["hidden"] // c["heads"], c["kv_heads"]
+    cache = KVCache(2, batch)
+    for l in range(2):
+        for s in range(batch):
+            cache.k[l][s] = torch.randn(ctx, nkv, hd, generator=g).to(torch.bfloat16)
+            cache.v[l][s] = torch.randn(ctx, nkv, hd, generator=g).to(torch.bfloat16)
+    ids = torch.randint(1000, 150000, (batch,), generator=g)
+    pos = torch.full((batch,), 40, dtype=torch.long)
+
+    def layers_only():
+        seq = o.embed(ids)
+        return o.llm_forward(seq, [1] * batch, pos, cache, True, True, "und")
+    with torch.no_grad():
+        h = layers_only()                     # warm-up
+        for l in range(2):                    # keep the context length fixed across timed steps
+            for s in range(batch):
+                cache.k[l][s] = cache.k[l][s][:ctx]; cache.v[l][s] = cache.v[l][s][:ctx]
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            h = layers_only()
+            for l in range(2):
+                for s in range(batch):
+                    cache.k[l][s] = cache.k[l][s][:ctx]; cache.v[l][s] = cache.v[l][s][:ctx]
+        t_layers = (time.perf_counter() - t0) / reps
+        o.lm_head(h)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lg = o.lm_head(h)
+            torch.argmax(lg, -1)
+        t_head = (time.perf_counter() - t0) / reps
+    step = t_layers / 2 * full_layers + t_head
+    return {
+        "value": round(batch / step, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle/unimedvl_cpu.py decode step, full width, 2 of {full_layers} layers + lm_head, B={batch}, "
+                  f"ctx={ctx}, {reps} reps; per-layer time x{full_layers} + head ({t_layers / 2 * 1e3:.1f} ms/layer, "
+                  f"{t_head * 1e3:.1f} ms head)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--config", default="full", choices=["full", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from unimedvl_amd import ops
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.decode import DecodeSession
+    from unimedvl_amd.kvcache import NaiveCache
+    from unimedvl_amd.weights import random_getter
+
+    if args.config == "full":
+        cfg = UniMedVLConfig()
+        img_hw, prompt_len = 448, 32
+    else:
+        from oracle.weights import TINY
+        cfg = UniMedVLConfig.from_dict(TINY)
+        img_hw, prompt_len = 56, 8
+    B = args.batch
+    t_load = time.time()
+    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=False, visual_und=True)
+    torch.cuda.synchronize()
+    t_load = time.time() - t_load
+
+    # ---- prefill: ViT encode + LLM prefill of the image span, then the question
+    new_token_ids = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2,
+                         end_of_image=cfg.vocab - 1)
+    g = torch.Generator().manual_seed(1234 + rank)
+    hi = min(150000, cfg.vocab - 8)
+    prompts = [torch.randint(min(1000, hi // 2), hi, (prompt_len,), generator=g).tolist() for _ in range(B)]
+    images = [synth_image(img_hw, img_hw, 1000 * rank + i) for i in range(B)]
+    cache = NaiveCache(cfg.layers)
+    kvl, rope = [0] * B, [0] * B
+    t0 = time.time()
+    gi, kvl, rope = model.prepare_vit_images(kvl, rope, images, lambda x: x, new_token_ids)
+    cache.reserve(B, max(kvl) + prompt_len + 2 + args.steps + args.warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
+    cache = model.forward_cache_update_vit(cache, **gi)
+    gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), new_token_ids)
+    cache = model.forward_cache_update_text(cache, **gi)
+    torch.cuda.synchronize()
+    t_prefill = time.time() - t0
+    ctx = kvl[0]
+
+    # ---- decode
+    gi = model.prepare_start_tokens(kvl, rope, new_token_ids)
+    total = args.warmup + args.steps
+    sess = DecodeSession(model.language_model, cache, gi["packed_start_tokens"], gi["packed_query_position_ids"],
+                         total + 1, use_graph=not args.no_graph)
+    sess.step(args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    sess.step(args.steps)
+    ids_local = sess.pred_ids[args.warmup:args.warmup + args.steps]
+    if dist is not None:   # C1: the only collective - gather every rank's generated ids over xGMI
+        gathered = [torch.empty_like(ids_local) for _ in range(world)]
+        dist.all_gather(gathered, ids_local.contiguous())
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    gpu_ms = e0.elapsed_time(e1)
+    sess.commit()
+    toks = ids_local.cpu()
+    assert toks.shape == (args.steps, B) and int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab
+
+    # ---- roofline of the dominant kernel: the weight-streaming skinny GEMM (gemm_skinny_kernel<1,2>:
+    # the 28 gate/up SwiGLU projections + lm_head of one step), HIP events on the launch stream
+    lw = model.language_model.w
+    x = torch.randn((B, cfg.hidden), device=dev).to(torch.bfloat16)
+    act = torch.empty((B, cfg.inter), dtype=torch.bfloat16, device=dev)
+    logits = torch.empty((B, cfg.vocab), dtype=torch.bfloat16, device=dev)
+
+    def dominant_pass():
+        for l in range(cfg.layers):
+            ops.gemm(x, lw.und[l].gate_up, out=act)
+        ops.gemm(x, lw.lm_head, out=logits)
+    dominant_pass()
+    torch.cuda.synchronize()
+    reps = 5
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(reps):
+        dominant_pass()
+    k1.record()
+    torch.cuda.synchronize()
+    launches = reps * (cfg.layers + 1)
+    avg_us = k0.elapsed_time(k1) * 1e3 / launches
+    # algorithmic bytes per launch: packed bf16 weight once + x + out
+    gu_bytes = 2 * cfg.inter * cfg.hidden * 2 + B * cfg.hidden * 2 + B * cfg.inter * 2
+    lm_bytes = cfg.vocab * cfg.hidden * 2 + B * cfg.hidden * 2 + B * cfg.vocab * 2
+    bytes_per_launch = (cfg.layers * gu_bytes + lm_bytes) / (cfg.layers + 1)
+    achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+    # whole-step algorithmic bytes (weights + KV read/write + logits), for the step-level fraction
+    kv_tok = cfg.layers * 2 * cfg.kv_heads * cfg.head_dim * 2
+    step_bytes = lw.decode_weight_bytes() + B * (ctx + args.warmup + args.steps / 2) * kv_tok + B * kv_tok + B * cfg.vocab * 2
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * args.steps / elapsed
+    out = {
+        "metric": "VQA greedy decode tokens/s, UniMedVL-14B (BAGEL-7B-MoT dims), batch 8 x 448x448 per GPU",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random N(0,0.02^2) weights at assumed 14B dims, synthetic images, random token ids)",
+        "config": {"workload": "configs[1]: UniMedVL-14B bf16 VQA greedy decode, batch=8 448x448, 1xMI355X"
+                               if args.config == "full" else "tiny smoke config",
+                   "batch_per_gpu": B, "context_tokens": ctx, "image": f"{img_hw}x{img_hw}", "prompt_tokens": prompt_len,
+                   "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
+                   "prefill_s": round(t_prefill, 3), "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                     "kernel": "gemm_skinny_kernel<1,2> (28 gate/up SwiGLU GEMMs + lm_head per step)",
+                     "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                     "step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                     "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
+        try:
+            out["cpu_baseline"] = cpu_baseline(B, ctx, cfg.layers)
+        except Exception as e:  # the baseline leg must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

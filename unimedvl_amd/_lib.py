@@ -93,6 +93,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); importing torch first makes
+    # the dynamic loader bind our library to THAT runtime instance, so device pointers and
+    # streams are shared.  Loading ours first would pull a second runtime from /opt/rocm.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise UmvError(
             f"{LIB_PATH} not found: build it with `python -m unimedvl_amd.build` "

@@ -477,5 +477,5 @@ class Bagel:
         gi = self.prepare_start_tokens(newlens, new_rope, new_token_ids)
         ids = self.generate_text(past_key_values=cache, max_length=max_length, do_sample=do_sample,
                                  temperature=temperature, end_token_id=new_token_ids["eos_token_id"], **gi)
-        output = tokenizer.decode(ids[:, 0])
+        output = tokenizer.decode(ids[:, 0].cpu())
         return output.split("<|im_end|>")[0].split("<|im_start|>")[1]

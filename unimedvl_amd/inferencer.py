@@ -1,0 +1,257 @@
+"""Interleaved text/image orchestration - drop-in for the reference's
+``InterleaveInferencer`` (codes/inferencer.py:31-680): same constructor, same methods,
+same keyword arguments and defaults, same return shapes.
+
+What changes underneath:
+  * contexts are snapshotted by copying only the used part of the KV slabs
+    (NaiveCache.__deepcopy__), and ``gen_text`` decodes on a copy exactly as the reference
+    does (inferencer.py:261), so the caller's context is never advanced by decoding;
+  * in understanding mode the reference still prefills the never-used ``cfg_img_context``
+    for every text item (inferencer.py:602); that work is skipped when
+    ``understanding_output=True`` because nothing ever reads it;
+  * all compute runs on the MI355X engine (unimedvl_amd.Bagel).
+"""
+from copy import deepcopy
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+from PIL import Image
+
+from .data_utils import pil_img2rgb
+from .kvcache import NaiveCache
+
+VLM_THINK_SYSTEM_PROMPT = '''You should first think about the reasoning process in the mind and then provide the user with the answer.
+The reasoning process is enclosed within <think> </think> tags, i.e. <think> reasoning process here </think> answer here'''
+
+GEN_THINK_SYSTEM_PROMPT = '''You should first think about the planning process in your mind, and then generate the image.
+The planning process is enclosed within <think> </think> tags; that is, <think> planning process here </think> image here.
+'''
+
+
+class InterleaveInferencer:
+    def __init__(self, model, vae_model, tokenizer, vae_transform, vit_transform, new_token_ids):
+        self.model = model
+        self.vae_model = vae_model
+        self.tokenizer = tokenizer
+        self.vae_transform = vae_transform
+        self.vit_transform = vit_transform
+        self.new_token_ids = new_token_ids
+
+    # ------------------------------------------------------------------ sizes
+    def _calculate_target_size_with_aspect_ratio(self, original_width, original_height):
+        """(height, width) the VAE transform would give this image (inferencer.py:42-71)."""
+        rt = self.vae_transform.resize_transform
+        max_size, min_size, stride, max_pixels = rt.max_size, rt.min_size, rt.stride, rt.max_pixels
+
+        def make_divisible(value):
+            return max(stride, int(round(value / stride) * stride))
+
+        def apply_scale(width, height, scale):
+            return make_divisible(round(width * scale)), make_divisible(round(height * scale))
+        scale = min(max_size / max(original_width, original_height), 1.0)
+        scale = max(scale, min_size / min(original_width, original_height))
+        new_width, new_height = apply_scale(original_width, original_height, scale)
+        if new_width * new_height > max_pixels:
+            new_width, new_height = apply_scale(new_width, new_height, max_pixels / (new_width * new_height))
+        if max(new_width, new_height) > max_size:
+            new_width, new_height = apply_scale(new_width, new_height, max_size / max(new_width, new_height))
+        return new_height, new_width
+
+    # ------------------------------------------------------------------ contexts
+    def init_gen_context(self):
+        return {"kv_lens": [0], "ropes": [0],
+                "past_key_values": NaiveCache(self.model.config.llm_config.num_hidden_layers)}
+
+    @torch.no_grad()
+    def update_context_text(self, text, gen_context):
+        gi, kv_lens, ropes = self.model.prepare_prompts(
+            curr_kvlens=gen_context["kv_lens"], curr_rope=gen_context["ropes"], prompts=[text],
+            tokenizer=self.tokenizer, new_token_ids=self.new_token_ids)
+        pkv = self.model.forward_cache_update_text(gen_context["past_key_values"], **gi)
+        gen_context["kv_lens"], gen_context["ropes"], gen_context["past_key_values"] = kv_lens, ropes, pkv
+        return gen_context
+
+    @torch.no_grad()
+    def update_context_image(self, image, gen_context, vae=True, vit=True):
+        assert vae or vit
+        pkv, kv_lens, ropes = gen_context["past_key_values"], gen_context["kv_lens"], gen_context["ropes"]
+        if vae:
+            gi, kv_lens, ropes = self.model.prepare_vae_images(
+                curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=self.vae_transform,
+                new_token_ids=self.new_token_ids)
+            pkv = self.model.forward_cache_update_vae(self.vae_model, pkv, **gi)
+        if vit:
+            gi, kv_lens, ropes = self.model.prepare_vit_images(
+                curr_kvlens=kv_lens, curr_rope=ropes, images=[image], transforms=self.vit_transform,
+                new_token_ids=self.new_token_ids)
+            pkv = self.model.forward_cache_update_vit(pkv, **gi)
+        gen_context["kv_lens"], gen_context["ropes"], gen_context["past_key_values"] = kv_lens, ropes, pkv
+        return gen_context
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def gen_image(self, image_shape, gen_context, cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_text_precontext=None,
+                  cfg_img_precontext=None, cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0, cfg_renorm_type="global",
+                  num_timesteps=50, timestep_shift=3.0):
+        m = self.model
+        gi = m.prepare_vae_latent(curr_kvlens=gen_context["kv_lens"], curr_rope=gen_context["ropes"],
+                                  image_sizes=[image_shape], new_token_ids=self.new_token_ids)
+        gt = m.prepare_vae_latent_cfg(curr_kvlens=cfg_text_precontext["kv_lens"], curr_rope=cfg_text_precontext["ropes"],
+                                      image_sizes=[image_shape])
+        gim = m.prepare_vae_latent_cfg(curr_kvlens=cfg_img_precontext["kv_lens"], curr_rope=cfg_img_precontext["ropes"],
+                                       image_sizes=[image_shape])
+        unpacked_latent = m.generate_image(
+            past_key_values=gen_context["past_key_values"],
+            cfg_text_past_key_values=cfg_text_precontext["past_key_values"],
+            cfg_img_past_key_values=cfg_img_precontext["past_key_values"],
+            num_timesteps=num_timesteps, cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale,
+            cfg_interval=cfg_interval, cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
+            timestep_shift=timestep_shift, **gi,
+            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+            cfg_img_packed_position_ids=gim["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=gim["cfg_packed_query_indexes"],
+            cfg_img_key_values_lens=gim["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=gim["cfg_packed_key_value_indexes"])
+        return self.decode_image(unpacked_latent[0], image_shape)
+
+    def decode_image(self, latent, image_shape):
+        """latent tokens [h*w, p*p*c] -> PIL (inferencer.py:234-256): unpatchify, VAE decode,
+        (x*0.5+0.5).clamp(0,1)*255 truncated to uint8."""
+        pixels = self.vae_model.decode_tokens_to_uint8(latent, image_shape, self.model.latent_downsample,
+                                                       self.model.latent_patch_size)
+        return Image.fromarray(pixels.cpu().numpy())
+
+    @torch.no_grad()
+    def gen_text(self, gen_context, max_length: int = 500, do_sample: bool = True, temperature: float = 1.0):
+        gen_context = deepcopy(gen_context)
+        gi = self.model.prepare_start_tokens(gen_context["kv_lens"], gen_context["ropes"], self.new_token_ids)
+        ids = self.model.generate_text(past_key_values=gen_context["past_key_values"], max_length=max_length,
+                                       do_sample=do_sample, temperature=temperature,
+                                       end_token_id=self.new_token_ids["eos_token_id"], **gi)
+        output = self.tokenizer.decode(ids[:, 0].cpu())
+        return output.split("<|im_end|>")[0].split("<|im_start|>")[1]
+
+    # ------------------------------------------------------------------ pipelines
+    @torch.no_grad()
+    def interleave_inference(self, input_lists: List[Union[str, Image.Image]], think=False, understanding_output=False,
+                             max_think_token_n=1000, do_sample=False, text_temperature=0.3, cfg_text_scale=3.0,
+                             cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), timestep_shift=3.0, num_timesteps=50,
+                             cfg_renorm_min=0.0, cfg_renorm_type="global", image_shapes=(1024, 1024)
+                             ) -> List[Union[str, Image.Image]]:
+        """inferencer.py:552-638."""
+        output_list = []
+        need_cfg = not understanding_output
+        gen_context = self.init_gen_context()
+        cfg_text_context = deepcopy(gen_context)
+        cfg_img_context = deepcopy(gen_context)
+        if think:
+            system_prompt = VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT
+            gen_context = self.update_context_text(system_prompt, gen_context)
+            if need_cfg:
+                cfg_img_context = self.update_context_text(system_prompt, cfg_img_context)
+        for input_term in input_lists:
+            if isinstance(input_term, str):
+                if need_cfg:
+                    cfg_text_context = deepcopy(gen_context)
+                gen_context = self.update_context_text(input_term, gen_context)
+                if need_cfg:
+                    cfg_img_context = self.update_context_text(input_term, cfg_img_context)
+            elif isinstance(input_term, Image.Image):
+                input_term = self.vae_transform.resize_transform(pil_img2rgb(input_term))
+                gen_context = self.update_context_image(input_term, gen_context, vae=not understanding_output)
+                if need_cfg:
+                    cfg_text_context = deepcopy(gen_context)
+            else:
+                raise ValueError(f"Unsupported input type: {type(input_term)}")
+        if understanding_output:
+            output_list.append(self.gen_text(gen_context, do_sample=do_sample, temperature=text_temperature,
+                                             max_length=max_think_token_n))
+        else:
+            if think:
+                gen_text = self.gen_text(gen_context, do_sample=do_sample, temperature=text_temperature,
+                                         max_length=max_think_token_n)
+                gen_context = self.update_context_text(gen_text, gen_context)
+                output_list.append(gen_text)
+            output_list.append(self.gen_image(
+                image_shapes, gen_context, cfg_text_precontext=cfg_text_context, cfg_img_precontext=cfg_img_context,
+                cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval,
+                timestep_shift=timestep_shift, num_timesteps=num_timesteps, cfg_renorm_min=cfg_renorm_min,
+                cfg_renorm_type=cfg_renorm_type))
+        return output_list
+
+    @torch.no_grad()
+    def interleave_inference_for_vqa_reconstruction_ver1(
+            self, input_lists: List[Union[str, Image.Image]], reconstruct_image: bool = False, think: bool = False,
+            understanding_output: bool = True, max_think_token_n: int = 1000, do_sample: bool = False,
+            text_temperature: float = 0.3, cfg_text_scale: float = 3.0, cfg_img_scale: float = 1.5,
+            cfg_interval: list = (0.4, 1.0), timestep_shift: float = 3.0, num_timesteps: int = 50,
+            cfg_renorm_min: float = 0.0, cfg_renorm_type: str = "global", image_shapes: tuple = (1024, 1024)
+    ) -> List[Union[str, Image.Image]]:
+        """VQA, then optionally reconstruct every input image from the answer (inferencer.py:282-362)."""
+        output_list = []
+        vqa_context = self.init_gen_context()
+        vqa_img_context = deepcopy(vqa_context)
+        for input_term in input_lists:
+            if isinstance(input_term, str):
+                vqa_context = self.update_context_text(input_term, vqa_context)
+                vqa_img_context = self.update_context_text(input_term, vqa_img_context)
+            elif isinstance(input_term, Image.Image):
+                processed = self.vae_transform.resize_transform(pil_img2rgb(input_term))
+                vqa_context = self.update_context_image(processed, vqa_context, vae=True, vit=True)
+            else:
+                raise ValueError(f"Unsupported input type: {type(input_term)}")
+        vqa_answer = self.gen_text(vqa_context, do_sample=do_sample, temperature=text_temperature,
+                                   max_length=max_think_token_n)
+        output_list.append(vqa_answer)
+        if not reconstruct_image or not vqa_answer or not vqa_answer.strip():
+            return output_list
+        input_images = [item for item in input_lists if isinstance(item, Image.Image)]
+        if not input_images:
+            return output_list
+        cfg_text_precontext = deepcopy(vqa_context)
+        cfg_img_precontext = self.update_context_text(vqa_answer, deepcopy(vqa_img_context))
+        full_context = self.update_context_text(vqa_answer, deepcopy(vqa_context))
+        for original_image in input_images:
+            w, h = original_image.size
+            target = self._calculate_target_size_with_aspect_ratio(w, h)
+            generated = self.gen_image(
+                target, full_context, cfg_text_precontext=cfg_text_precontext, cfg_img_precontext=cfg_img_precontext,
+                cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval,
+                cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type, num_timesteps=num_timesteps,
+                timestep_shift=timestep_shift)
+            output_list.append(generated)
+            processed = self.vae_transform.resize_transform(pil_img2rgb(generated))
+            full_context = self.update_context_image(processed, full_context, vae=True, vit=False)
+            cfg_text_precontext = self.update_context_image(processed, cfg_text_precontext, vae=True, vit=False)
+        return output_list
+
+    def __call__(self, image: Optional[Union[Image.Image, List[Image.Image]]] = None, text: Optional[str] = None,
+                 inference_ver=0, **kargs) -> Dict[str, Any]:
+        """inferencer.py:640-680: images first, then the text; {'image': PIL|list|None, 'text': str|None}."""
+        output_dict = {"image": None, "text": None}
+        if image is None and text is None:
+            return output_dict
+        input_list = []
+        if image is not None:
+            input_list.extend(image if isinstance(image, list) else [image])
+        if text is not None:
+            input_list.append(text)
+        if inference_ver == 0:
+            output_list = self.interleave_inference(input_list, **kargs)
+        elif inference_ver == 1:
+            output_list = self.interleave_inference_for_vqa_reconstruction_ver1(input_list, **kargs)
+        else:
+            raise ValueError(f"Unsupported inference_ver: {inference_ver}")
+        for item in output_list:
+            if isinstance(item, Image.Image):
+                if output_dict["image"] is None:
+                    output_dict["image"] = []
+                output_dict["image"].append(item)
+            elif isinstance(item, str):
+                output_dict["text"] = item
+        if isinstance(output_dict["image"], list) and len(output_dict["image"]) == 1:
+            output_dict["image"] = output_dict["image"][0]
+        return output_dict
