@@ -158,6 +158,37 @@ int umv_cfg_renorm_euler(float* x_t, const uint16_t* v_t, const uint16_t* v_text
                          const int32_t* rows, const int32_t* seg_off, int nseg, float cfg_text_scale,
                          float cfg_img_scale, float renorm_min, int renorm_type, float dt, int D, umv_stream_t stream);
 
+/* ------------------------------------------------------------------ VAE (FLUX autoencoder, autoencoder.py)
+ * Activations are NHWC bf16 ([B,H,W,C], C % 8 == 0).  Convolution weights [Cout,Cin,k,k] are
+ * permuted to [Cout,(ky,kx,ci)] and packed with umv_pack_weight_bf16 (N=Cout, K=k*k*Cin).
+ * umv_conv2d_nhwc_bf16 = F.conv2d (+bias, + optional residual x + h of ResnetBlock/AttnBlock,
+ * autoencoder.py:95,65) as an MFMA implicit GEMM:
+ *   mode 0: stride 1, pad (k-1)/2            (autoencoder.py:76,78,80,138,167,214,238)
+ *   mode 1: nearest 2x upsample then 3x3     (Upsample, autoencoder.py:116-118)
+ *   mode 2: F.pad(0,1,0,1) then 3x3 stride 2 (Downsample, autoencoder.py:104-107) */
+int umv_conv2d_nhwc_bf16(const uint16_t* x, const uint16_t* wp, const uint16_t* bias, const uint16_t* residual,
+                         uint16_t* out, int B, int Cin, int Hin, int Win, int Cout, int ksize, int mode,
+                         umv_stream_t stream);
+/* nn.GroupNorm(32, C, eps, affine) on bf16 with optional swish x*sigmoid(x) (autoencoder.py:34-35,
+ * 43,75,77,166,237); deterministic two-level reduction through `workspace`. */
+size_t umv_groupnorm_workspace_bytes(int B, int HW);
+int umv_groupnorm_nhwc_bf16(const uint16_t* x, const uint16_t* gamma, const uint16_t* beta, uint16_t* out, void* workspace,
+                            int B, int HW, int C, float eps, int swish, umv_stream_t stream);
+/* [B,C,H,W] fp32 -> NHWC bf16 with channels zero padded to Cp (input of encoder.conv_in) */
+int umv_nchw_f32_to_nhwc_bf16(const float* x, uint16_t* out, int B, int C, int H, int W, int Cp, umv_stream_t stream);
+/* latent tokens [h*w, p*p*c] fp32 -> NHWC bf16 [h*p, w*p, c] with z/scale + shift
+ * (inferencer.py:239-241 unpatchify + autoencoder.py:306) */
+int umv_unpatchify_latent(const float* tokens, uint16_t* out, int h, int w, int p, int c, float scale, float shift,
+                          umv_stream_t stream);
+/* decoder output NHWC bf16 (first 3 of Cs channels) -> uint8 HWC: (x*0.5+0.5).clamp(0,1)*255,
+ * truncating cast (inferencer.py:253-254) */
+int umv_pixels_to_u8(const uint16_t* x, uint8_t* out, int64_t npix, int Cs, umv_stream_t stream);
+/* encoder tail for sample b: moments NHWC [B,Hm,Wm,2z] + noise NCHW bf16 [B,z,Hm,Wm] ->
+ * scale*(mean + exp(0.5*logvar)*noise - shift) (autoencoder.py:266-272,300-303), 2x2-patchified
+ * tokens [h*w, p*p*z] of the top-left window (bagel.py:771-775) */
+int umv_latent_sample_patchify(const uint16_t* moments, const uint16_t* noise, uint16_t* tokens, int b, int Hm, int Wm,
+                               int z, int h, int w, int p, float scale, float shift, umv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,140 @@
+"""VAE kernels and the image paths that use them, against reference goldens / the oracle.
+Tolerances: VAE activations go through ~30 bf16 conv+GroupNorm stages; decoded images in
+[-1,1]-ish units are compared at atol 0.06 (max) / 0.01 (mean); uint8 pixels within +-4 on
+>= 99% of pixels (the reference's bf16 *255 quantises to 1-2 grey levels above 128)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, NEW_TOKEN_IDS
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def vae(tiny_weights):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.vae import AutoEncoder
+    cfg, sd, vae_sd, _ = tiny_weights
+    return AutoEncoder(UniMedVLConfig.from_dict(cfg), lambda n: vae_sd[n], device="cuda")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF16)
+
+
+@pytest.mark.parametrize("mode,cin,cout,h,w", [(0, 16, 128, 8, 8), (0, 128, 64, 13, 9), (1, 64, 64, 6, 10),
+                                               (2, 32, 32, 16, 12), (2, 32, 32, 15, 11), (0, 8, 32, 20, 20)])
+def test_conv3x3(mode, cin, cout, h, w):
+    from unimedvl_amd import _lib
+    from unimedvl_amd.vae import _Conv, _stream
+    lib = _lib.load()
+    x = rnd((2, cin, h, w), 1)
+    wt, b = rnd((cout, cin, 3, 3), 2, 1 / (3 * cin ** 0.5)), rnd((cout,), 3, 0.1)
+    res = None
+    if mode == 0:
+        ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1)
+    elif mode == 1:
+        ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), wt.float(), b.float(), padding=1)
+    else:
+        ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), wt.float(), b.float(), stride=2)
+    ref = ref.to(BF16)
+    if mode == 0:
+        res = rnd(tuple(ref.shape), 4)
+        ref = ref + res
+    c = _Conv(wt, b, "cuda")
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.empty((2, Ho, Wo, cout), dtype=BF16, device="cuda")
+    resn = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+    _lib.check(lib.umv_conv2d_nhwc_bf16(xn.data_ptr(), c.lin.wp.data_ptr(), c.bias.data_ptr(),
+                                        None if resn is None else resn.data_ptr(), out.data_ptr(), 2, cin, h, w, cout, 3,
+                                        mode, _stream()), "conv")
+    got = out.cpu().permute(0, 3, 1, 2).float()
+    err = (got - ref.float()).abs().max().item()
+    assert err <= 2 ** -6 * max(1.0, ref.float().abs().max().item()), f"conv mode {mode}: max err {err}"
+
+
+@pytest.mark.parametrize("C,hw,swish", [(32, 64, True), (128, 300, True), (512, 1024, False), (64, 257, True)])
+def test_groupnorm(vae, C, hw, swish):
+    from unimedvl_amd import _lib
+    from unimedvl_amd.vae import _stream
+    lib = _lib.load()
+    x = rnd((2, C, hw, 1), 5, 2.0)
+    g, b = rnd((C,), 6) + 1, rnd((C,), 7)
+    ref = F.group_norm(x, 32, g, b, 1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.empty_like(xn)
+    ws = torch.empty(lib.umv_groupnorm_workspace_bytes(2, hw) // 4 + 16, dtype=torch.float32, device="cuda")
+    gd, bd = g.cuda(), b.cuda()   # keep the device copies alive across the asynchronous launch
+    _lib.check(lib.umv_groupnorm_nhwc_bf16(xn.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+                                           ws.data_ptr(), 2, hw, C, 1e-6, int(swish), _stream()), "gn")
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2).float()
+    d = (got - ref.float()).abs()
+    tol = 2 ** -6 * ref.float().abs().clamp_min(1.0)     # 2 bf16 ulp of the value
+    assert bool((d <= tol).all()) and d.mean().item() < 3e-3, f"groupnorm C={C}: max {d.max().item()} mean {d.mean().item()}"
+
+
+def test_attention_hd512():
+    from unimedvl_amd import ops
+    from oracle.unimedvl_cpu import attention_segment
+    n, hd = 200, 512
+    q, k, v = rnd((n, 1, hd), 8, 0.3), rnd((n, 1, hd), 9, 0.3), rnd((n, 1, hd), 10)
+    slab = ops.KVSlab(1, 1, 224, hd, "cuda")
+    kh, vh = slab.k.cpu(), slab.vt.cpu()
+    kh[0, :, :n] = k.transpose(0, 1)
+    vh[0, :, :, :n] = v.permute(1, 2, 0)
+    slab.k.copy_(kh); slab.vt.copy_(vh)
+    out = torch.zeros((n, 1, hd), dtype=BF16, device="cuda")
+    ops.attention(q.cuda(), out, slab, torch.tensor([0, n], dtype=torch.int32).cuda(),
+                  torch.tensor([n], dtype=torch.int32).cuda(), 1, 1, hd, False, n, n)
+    ref = attention_segment(q, k, v, False, impl="flash")
+    err = (out.cpu().float() - ref.float()).abs().max().item()
+    assert err < 0.03, err
+
+
+def test_vae_decode_encode_vs_reference(vae):
+    g = load_golden("vae")
+    dec = vae.decode(g["z"].to(BF16)).float().cpu()
+    d = (dec - g["decoded"].float()).abs()
+    assert d.max().item() < 0.06 and d.mean().item() < 0.01, f"decode: max {d.max().item()} mean {d.mean().item()}"
+    enc = vae.encode(g["image"], noise=g["enc_noise"]).float().cpu()
+    d = (enc - g["encoded"].float()).abs()
+    assert d.max().item() < 0.06 and d.mean().item() < 0.01, f"encode: max {d.max().item()} mean {d.mean().item()}"
+
+
+def test_t2i_pixels_vs_reference(vae, tiny_weights):
+    g = load_golden("t2i")
+    H, W = g["image_shape"].tolist()
+    cfg = tiny_weights[0]
+    down = 2 ** (len(cfg["vae_mult"]) - 1) * cfg["latent_patch"]
+    px = vae.decode_tokens_to_uint8(g["latent_global"], (H, W), down, cfg["latent_patch"]).cpu()
+    ref = g["pixels_u8"]
+    assert px.shape == ref.shape
+    diff = (px.int() - ref.int()).abs()
+    assert (diff <= 4).float().mean().item() >= 0.99 and diff.max().item() <= 16, \
+        f"pixels: {100 * (diff <= 4).float().mean().item():.2f}% within 4, max {diff.max().item()}"
+
+
+def test_edit_prefill_vs_reference(vae, tiny_weights):
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.kvcache import NaiveCache
+    cfg, sd, _, _ = tiny_weights
+    model = Bagel(UniMedVLConfig.from_dict(cfg), lambda n: sd[n], device="cuda")
+    g = load_golden("edit_prefill")
+    cache = NaiveCache(cfg["layers"])
+    gi, kvl, rope = model.prepare_vae_images([0], [0], [g["image"]], lambda x: x, NEW_TOKEN_IDS)
+    cache = model.forward_cache_update_vae(vae, cache, noise=g["enc_noise"], **gi)
+    assert kvl == g["kv_lens"].tolist() and rope == g["ropes"].tolist()
+    k0, vL = cache.packed_keys(0).float().cpu(), cache.packed_values(cfg["layers"] - 1).float().cpu()
+    for got, ref, name in ((k0, g["k0"].float(), "k0"), (vL, g["vL"].float(), "vL")):
+        err = (got - ref).abs().max().item()
+        assert err <= 3e-2 * ref.abs().max().item(), f"{name}: max err {err} vs scale {ref.abs().max().item()}"

@@ -217,8 +217,10 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
         hipLaunchKernelGGL((attn_kernel<128>), grid, block, 0, s, a, scale_log2e);
     else if (a.hd == 72)
         hipLaunchKernelGGL((attn_kernel<72>), grid, block, 0, s, a, scale_log2e);
+    else if (a.hd == 512 && a.nsplit == 1)   // VAE mid-block attention, single head of 512 (autoencoder.py:50-62)
+        hipLaunchKernelGGL((attn_kernel<512>), grid, block, 0, s, a, scale_log2e);
     else
-        UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "attn: head_dim %d unsupported (128, 72)", a.hd);
+        UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "attn: head_dim %d unsupported (128, 72, 512)", a.hd);
     UMV_LAUNCH_CHECK();
     if (a.nsplit > 1) {
         // grid over the static bound nseg*max_q tokens; rows beyond cu_q[nseg]*nq exit on device

@@ -332,6 +332,30 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
     }
 }
 
+// No norm / no RoPE (ViT, VAE mid-block attention): split the fused QKV row into q rows and
+// K / V^T slab entries, any head_dim.
+__global__ __launch_bounds__(256) void qkv_split_kernel(umv_qkv_post_args a) {
+    const int lane = threadIdx.x & 63;
+    const int HD = a.hd;
+    const int nheads = a.nq + 2 * a.nkv;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (int64_t)a.T * nheads) return;
+    const int t = (int)(item / nheads);
+    const int h = (int)(item % nheads);
+    const bf16_t* src = a.qkv + (int64_t)t * nheads * HD + (int64_t)h * HD;
+    const int seg = a.tok_seg[t], slot = a.tok_slot[t];
+    if (h < a.nq) {
+        bf16_t* dst = a.q_out + (int64_t)t * a.nq * HD + (int64_t)h * HD;
+        for (int d = lane; d < HD; d += 64) dst[d] = src[d];
+    } else if (h < a.nq + a.nkv) {
+        bf16_t* dst = a.k_slab + seg * a.k_seg_stride + (h - a.nq) * a.k_head_stride + (int64_t)slot * HD;
+        for (int d = lane; d < HD; d += 64) dst[d] = src[d];
+    } else {
+        bf16_t* dst = a.vt_slab + seg * a.v_seg_stride + (h - a.nq - a.nkv) * a.v_head_stride + slot;
+        for (int d = lane; d < HD; d += 64) dst[(int64_t)d * a.v_d_stride] = src[d];
+    }
+}
+
 extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap, UMV_ERR_ARG, "qkv_post: null args");
     const umv_qkv_post_args& a = *ap;
@@ -341,7 +365,9 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     if (a.T == 0) return UMV_OK;
     int64_t items = (int64_t)a.T * (a.nq + 2 * a.nkv);
     dim3 grid((unsigned)((items + 3) / 4)), block(256);
-    if (a.hd == 128)
+    if (!a.q_norm_w)
+        hipLaunchKernelGGL(qkv_split_kernel, grid, block, 0, (hipStream_t)stream, a);
+    else if (a.hd == 128)
         hipLaunchKernelGGL((qkv_post_kernel<128>), grid, block, 0, (hipStream_t)stream, a);
     else if (a.hd == 72)
         hipLaunchKernelGGL((qkv_post_kernel<72>), grid, block, 0, (hipStream_t)stream, a);

@@ -118,3 +118,382 @@ extern "C" int umv_cfg_renorm_euler(float* x_t, const uint16_t* v_t, const uint1
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
+
+// ----------------------------------------------------------------------------- VAE: implicit-GEMM convolution
+// NHWC bf16 activations.  out[b,oy,ox,co] = bias[co] + sum_{ky,kx,ci} in[b,iy,ix,ci] * W[co][ky][kx][ci]
+// is the GEMM  out[m = pixel][n = co] = sum_k x[m][k] Wp[n][k]  with k = (ky*ks+kx)*Cin + ci,
+// so it reuses the packed-weight MFMA tile of gemm.hip: W is the A operand streamed from the
+// packed image, the im2col row fragment (8 consecutive ci of one tap = 16 contiguous bytes,
+// Cin % 8 == 0) is gathered straight into the LDS B-fragment image - no im2col buffer.
+// mode 0: stride 1, pad (ks-1)/2 (autoencoder.py:76,78,138,167,214,238)
+// mode 1: nearest 2x upsample fused into the gather (Upsample, autoencoder.py:116-118)
+// mode 2: stride 2 after F.pad(0,1,0,1), no other padding (Downsample, autoencoder.py:104-107)
+struct ConvGeom {
+    int B, Cin, Hin, Win, Cout, Hout, Wout, ks, mode;
+};
+
+#define CV_BM 128
+#define CV_BN 128
+__global__ __launch_bounds__(256) void conv_tiled_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                         bf16_t* __restrict__ out, ConvGeom geo, int KT, int NTT, int mblocks) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[2][CV_BM / 16][64][8];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int mblk = blockIdx.x % mblocks;
+    const int nblk = blockIdx.x / mblocks;
+    const int m0 = mblk * CV_BM;
+    const int nt_base = nblk * (CV_BN / 16) + wn * 4;
+    const int M = geo.B * geo.Hout * geo.Wout;
+    const int K = geo.ks * geo.ks * geo.Cin;
+
+    // staging role: fragment f = tid + i*256 -> (m-tile, lane)
+    int sb[2], soy[2], sox[2], skg[2];
+    bool svalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = tid + i * 256;
+        int mt = f >> 6, l = f & 63;
+        int m = m0 + mt * 16 + (l & 15);
+        svalid[i] = m < M;
+        int mm = svalid[i] ? m : 0;
+        sb[i] = mm / (geo.Hout * geo.Wout);
+        int rem = mm % (geo.Hout * geo.Wout);
+        soy[i] = rem / geo.Wout;
+        sox[i] = rem % geo.Wout;
+        skg[i] = (l >> 4) * 8;
+    }
+    auto gather = [&](int i, int kt) -> bf16x8 {
+        const int k = kt * 32 + skg[i];
+        if (!svalid[i] || k >= K) return zero_frag();
+        const int tap = k / geo.Cin, ci = k % geo.Cin;
+        const int ky = tap / geo.ks, kx = tap % geo.ks;
+        int iy, ix;
+        if (geo.mode == 0) {
+            const int pad = (geo.ks - 1) >> 1;
+            iy = soy[i] + ky - pad; ix = sox[i] + kx - pad;
+            if (iy < 0 || iy >= geo.Hin || ix < 0 || ix >= geo.Win) return zero_frag();
+        } else if (geo.mode == 1) {
+            iy = soy[i] + ky - 1; ix = sox[i] + kx - 1;       // coordinates in the 2x upsampled image
+            if (iy < 0 || iy >= 2 * geo.Hin || ix < 0 || ix >= 2 * geo.Win) return zero_frag();
+            iy >>= 1; ix >>= 1;
+        } else {
+            iy = 2 * soy[i] + ky; ix = 2 * sox[i] + kx;       // zero pad on the bottom / right only
+            if (iy >= geo.Hin || ix >= geo.Win) return zero_frag();
+        }
+        return ldg_frag(x + (((int64_t)sb[i] * geo.Hin + iy) * geo.Win + ix) * geo.Cin + ci);
+    };
+    const bf16_t* wbase[4];
+    bool tvalid[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        tvalid[t] = (nt_base + t) < NTT;
+        wbase[t] = wp + ((int64_t)(tvalid[t] ? nt_base + t : 0) * KT) * 512 + lane * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 stage[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) stage[i] = gather(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = tid + i * 256;
+        *reinterpret_cast<bf16x8*>(&xs[0][f >> 6][f & 63][0]) = stage[i];
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) stage[i] = gather(i, kt + 1);
+        }
+        bf16x8 wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = ldg_frag(wbase[t] + (int64_t)kt * 512);
+        bf16x8 xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(&xs[cur][wm * 4 + j][lane][0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int f = tid + i * 256;
+                *reinterpret_cast<bf16x8*>(&xs[cur ^ 1][f >> 6][f & 63][0]) = stage[i];
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: + bias -> bf16 ; (+ residual -> bf16)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (wm * 4 + j) * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n0 = (nt_base + t) * 16 + g * 4;
+            if (n0 >= geo.Cout) continue;
+            float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (n0 + q >= geo.Cout) continue;
+                float o = rbf(v[q] + (bias ? bf2f(bias[n0 + q]) : 0.f));
+                if (residual) o = rbf(o + bf2f(residual[(int64_t)m * geo.Cout + n0 + q]));
+                out[(int64_t)m * geo.Cout + n0 + q] = f2bf(o);
+            }
+        }
+    }
+}
+
+extern "C" int umv_conv2d_nhwc_bf16(const uint16_t* x, const uint16_t* wp, const uint16_t* bias, const uint16_t* residual,
+                                    uint16_t* out, int B, int Cin, int Hin, int Win, int Cout, int ksize, int mode,
+                                    umv_stream_t stream) {
+    UMV_CHECK(x && wp && out, UMV_ERR_ARG, "conv2d: null pointer");
+    UMV_CHECK(Cin % 8 == 0, UMV_ERR_ARG, "conv2d: Cin (%d) must be a multiple of 8 (pad the input channels)", Cin);
+    UMV_CHECK((ksize == 3 || ksize == 1) && mode >= 0 && mode <= 2, UMV_ERR_ARG, "conv2d: ksize %d mode %d", ksize, mode);
+    ConvGeom geo;
+    geo.B = B; geo.Cin = Cin; geo.Hin = Hin; geo.Win = Win; geo.Cout = Cout; geo.ks = ksize; geo.mode = mode;
+    if (mode == 0) { geo.Hout = Hin; geo.Wout = Win; }
+    else if (mode == 1) { geo.Hout = 2 * Hin; geo.Wout = 2 * Win; }
+    else { geo.Hout = (Hin + 1 - 3) / 2 + 1; geo.Wout = (Win + 1 - 3) / 2 + 1; }
+    const int M = B * geo.Hout * geo.Wout;
+    if (M == 0) return UMV_OK;
+    const int K = ksize * ksize * Cin;
+    const int KT = (K + 31) / 32, NTT = (Cout + 15) / 16;
+    const int mblocks = (M + CV_BM - 1) / CV_BM, nblocks = (Cout + CV_BN - 1) / CV_BN;
+    hipLaunchKernelGGL(conv_tiled_kernel, dim3(mblocks * nblocks), dim3(256), 0, (hipStream_t)stream, x, wp, bias, residual, out,
+                       geo, KT, NTT, mblocks);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- VAE: GroupNorm(32) (+ swish), NHWC
+// F.group_norm on bf16 (autoencoder.py:75,77,166,237,43) then swish x*sigmoid(x) (:34-35): fp32
+// statistics over (H*W, C/32) per (sample, group), one bf16 rounding of the normalised value,
+// sigmoid rounded to bf16, product rounded to bf16.  Deterministic two-level reduction:
+// pass 1 writes per-chunk partial sums, pass 2 folds them in a fixed order and applies.
+#define GN_CHUNK 256   // pixels per partial-sum workgroup
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                         int nchunks) {
+    // grid (nchunks, B); thread t owns channel octets t, t+256, ... ; cpg = C/32 channels per group
+    extern __shared__ float sm[];   // [2][C]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * GN_CHUNK, p1 = min(HW, p0 + GN_CHUNK);
+    const int nv = C / 8;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+    __syncthreads();
+    // each thread walks (pixel, octet) pairs with a fixed assignment -> deterministic
+    const int per_row = nv;
+    const int lanes = blockDim.x;
+    // thread handles octet (tid % per_row) when per_row <= lanes, striding pixels by lanes/per_row
+    if (per_row <= lanes) {
+        const int oct = threadIdx.x % per_row, prow = threadIdx.x / per_row, pstride = lanes / per_row;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (prow < pstride) {
+            for (int p = p0 + prow; p < p1; p += pstride) {
+                bf16x8 v = ldg_frag(x + ((int64_t)b * HW + p) * C + oct * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = bf2f((bf16_t)v[j]); s[j] += f; q[j] += f * f; }
+            }
+        }
+        // fold pixel-rows in a fixed order through LDS
+        for (int pr = 0; pr < pstride; ++pr) {
+            if (prow == pr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sm[oct * 8 + j] += s[j]; sm[C + oct * 8 + j] += q[j]; }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int oct = threadIdx.x; oct < per_row; oct += lanes) {
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int p = p0; p < p1; ++p) {
+                bf16x8 v = ldg_frag(x + ((int64_t)b * HW + p) * C + oct * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = bf2f((bf16_t)v[j]); s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sm[oct * 8 + j] = s[j]; sm[C + oct * 8 + j] = q[j]; }
+        }
+        __syncthreads();
+    }
+    // per-group sums for this chunk
+    const int cpg = C / 32;
+    if (threadIdx.x < 32) {
+        float s = 0.f, q = 0.f;
+        for (int c = 0; c < cpg; ++c) { s += sm[threadIdx.x * cpg + c]; q += sm[C + threadIdx.x * cpg + c]; }
+        float* dst = part + (((int64_t)b * nchunks + chunk) * 32 + threadIdx.x) * 2;
+        dst[0] = s; dst[1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ part,
+                                                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                       bf16_t* __restrict__ out, int HW, int C, int nchunks, float eps, int swish) {
+    __shared__ float mean_s[32], rstd_s[32];
+    const int b = blockIdx.y;
+    const int cpg = C / 32;
+    if (threadIdx.x < 32) {
+        float s = 0.f, q = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const float* p = part + (((int64_t)b * nchunks + ch) * 32 + threadIdx.x) * 2;
+            s += p[0]; q += p[1];
+        }
+        const float n = (float)HW * (float)cpg;
+        const float mean = s / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        mean_s[threadIdx.x] = mean;
+        rstd_s[threadIdx.x] = rsqrt_ieee(var + eps);
+    }
+    __syncthreads();
+    const int nv = C / 8;
+    const int64_t total = (int64_t)HW * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oct = (int)(i % nv);
+        const int64_t p = i / nv;
+        const int64_t off = ((int64_t)b * HW + p) * C + oct * 8;
+        bf16x8 v = ldg_frag(x + off), gm = ldg_frag(gamma + oct * 8), bt = ldg_frag(beta + oct * 8), o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int grp = (oct * 8 + j) / cpg;
+            float y = rbf((bf2f((bf16_t)v[j]) - mean_s[grp]) * rstd_s[grp] * bf2f((bf16_t)gm[j]) + bf2f((bf16_t)bt[j]));
+            if (swish) {
+                float sg = rbf(1.0f / (1.0f + expf(-y)));
+                y = rbf(y * sg);
+            }
+            o[j] = (short)f2bf(y);
+        }
+        *reinterpret_cast<bf16x8*>(out + off) = o;
+    }
+}
+
+extern "C" size_t umv_groupnorm_workspace_bytes(int B, int HW) {
+    return (size_t)B * ((HW + GN_CHUNK - 1) / GN_CHUNK) * 32 * 2 * sizeof(float);
+}
+
+extern "C" int umv_groupnorm_nhwc_bf16(const uint16_t* x, const uint16_t* gamma, const uint16_t* beta, uint16_t* out, void* workspace,
+                                       int B, int HW, int C, float eps, int swish, umv_stream_t stream) {
+    UMV_CHECK(x && gamma && beta && out && workspace, UMV_ERR_ARG, "groupnorm: null pointer");
+    UMV_CHECK(C % 32 == 0 && C % 8 == 0, UMV_ERR_ARG, "groupnorm: C=%d must be a multiple of 32", C);
+    if (B == 0 || HW == 0) return UMV_OK;
+    const int nchunks = (HW + GN_CHUNK - 1) / GN_CHUNK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, B), dim3(256), 2 * C * sizeof(float), s, x, (float*)workspace, HW, C, nchunks);
+    UMV_LAUNCH_CHECK();
+    int blocks = (int)min((int64_t)2048, ((int64_t)HW * (C / 8) + 255) / 256);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x, (const float*)workspace, gamma, beta, out, HW, C, nchunks,
+                       eps, swish);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- VAE: layout / boundary kernels
+// image [B,3,H,W] fp32 NCHW -> NHWC bf16 with channels zero padded to Cp (autocast's cast before conv_in)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int H, int W, int Cp) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)B * H * W * Cp;
+    if (gid >= total) return;
+    int c = (int)(gid % Cp);
+    int64_t p = gid / Cp;
+    int xw = (int)(p % W);
+    int y = (int)((p / W) % H);
+    int b = (int)(p / ((int64_t)W * H));
+    out[gid] = c < C ? f2bf(x[(((int64_t)b * C + c) * H + y) * W + xw]) : (bf16_t)0;
+}
+extern "C" int umv_nchw_f32_to_nhwc_bf16(const float* x, uint16_t* out, int B, int C, int H, int W, int Cp, umv_stream_t stream) {
+    UMV_CHECK(x && out && Cp >= C, UMV_ERR_ARG, "nchw_to_nhwc: bad args");
+    int64_t total = (int64_t)B * H * W * Cp;
+    if (total == 0) return UMV_OK;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, C, H, W, Cp);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// latent tokens [h*w, p*p*c] (fp32 x_t or bf16) -> NHWC bf16 [1, h*p, w*p, c] with z/scale + shift
+// (inferencer.py:239-241 "nhwpqc->nchpwq" and autoencoder.py:306), bf16 rounding per op.
+__global__ void unpatchify_latent_kernel(const float* __restrict__ tok, bf16_t* __restrict__ out, int h, int w, int p, int c,
+                                         float scale, float shift) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)h * p * w * p * c;
+    if (gid >= total) return;
+    int ch = (int)(gid % c);
+    int64_t pix = gid / c;
+    int X = (int)(pix % (w * p)), Y = (int)(pix / (w * p));
+    int hy = Y / p, py = Y % p, wx = X / p, px = X % p;
+    float v = rbf(tok[((int64_t)hy * w + wx) * (p * p * c) + (py * p + px) * c + ch]);   // latent.to(bf16)
+    v = rbf(rbf(v / scale) + shift);
+    out[gid] = f2bf(v);
+}
+extern "C" int umv_unpatchify_latent(const float* tokens, uint16_t* out, int h, int w, int p, int c, float scale, float shift,
+                                     umv_stream_t stream) {
+    UMV_CHECK(tokens && out, UMV_ERR_ARG, "unpatchify_latent: null pointer");
+    int64_t total = (int64_t)h * p * w * p * c;
+    if (total == 0) return UMV_OK;
+    hipLaunchKernelGGL(unpatchify_latent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tokens, out,
+                       h, w, p, c, scale, shift);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// decoder output NHWC bf16 [H,W,Cs] (first 3 channels) -> uint8 [H,W,3]:
+// ((x*0.5+0.5).clamp(0,1))*255 in bf16, truncating cast (inferencer.py:253-254)
+__global__ void pixels_u8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ out, int64_t npix, int Cs) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= npix * 3) return;
+    int c = (int)(gid % 3);
+    int64_t p = gid / 3;
+    float v = bf2f(x[p * Cs + c]);
+    v = rbf(rbf(v * 0.5f) + 0.5f);
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    v = rbf(v * 255.0f);
+    out[gid] = (uint8_t)v;
+}
+extern "C" int umv_pixels_to_u8(const uint16_t* x, uint8_t* out, int64_t npix, int Cs, umv_stream_t stream) {
+    UMV_CHECK(x && out && Cs >= 3, UMV_ERR_ARG, "pixels_to_u8: bad args");
+    if (npix == 0) return UMV_OK;
+    hipLaunchKernelGGL(pixels_u8_kernel, dim3((unsigned)((npix * 3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, npix, Cs);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// encoder tail: moments NHWC bf16 [B,Hm,Wm,2z] -> z = mean + exp(0.5*logvar)*noise ; scale*(z - shift)
+// (autoencoder.py:266-272,300-303) then 2x2 patchify "chpwq->hwpqc" of the top-left h*p x w*p window
+// (bagel.py:771-775) -> tokens bf16 [h*w, p*p*z].  noise is NCHW bf16 [B,z,Hm,Wm] as torch.randn_like draws it.
+__global__ void latent_sample_patchify_kernel(const bf16_t* __restrict__ mom, const bf16_t* __restrict__ noise, bf16_t* __restrict__ tok,
+                                              int b, int Hm, int Wm, int z, int h, int w, int p, float scale, float shift) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)h * w * p * p * z;
+    if (gid >= total) return;
+    int ch = (int)(gid % z);
+    int64_t r = gid / z;
+    int px = (int)(r % p); r /= p;
+    int py = (int)(r % p); r /= p;
+    int wx = (int)(r % w);
+    int hy = (int)(r / w);
+    int Y = hy * p + py, X = wx * p + px;
+    const bf16_t* m = mom + (((int64_t)b * Hm + Y) * Wm + X) * (2 * z);
+    float mean = bf2f(m[ch]), logvar = bf2f(m[z + ch]);
+    float stdv = rbf(expf(rbf(0.5f * logvar)));
+    float nz = bf2f(noise[(((int64_t)b * z + ch) * Hm + Y) * Wm + X]);
+    float zz = rbf(mean + rbf(stdv * nz));
+    zz = rbf(scale * rbf(zz - shift));
+    tok[gid] = f2bf(zz);
+}
+extern "C" int umv_latent_sample_patchify(const uint16_t* moments, const uint16_t* noise, uint16_t* tokens, int b, int Hm, int Wm,
+                                          int z, int h, int w, int p, float scale, float shift, umv_stream_t stream) {
+    UMV_CHECK(moments && noise && tokens, UMV_ERR_ARG, "latent_sample_patchify: null pointer");
+    UMV_CHECK(h * p <= Hm && w * p <= Wm, UMV_ERR_ARG, "latent_sample_patchify: window exceeds the latent");
+    int64_t total = (int64_t)h * w * p * p * z;
+    if (total == 0) return UMV_OK;
+    hipLaunchKernelGGL(latent_sample_patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, moments,
+                       noise, tokens, b, Hm, Wm, z, h, w, p, scale, shift);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
