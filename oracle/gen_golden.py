@@ -234,15 +234,63 @@ def main():
         torch.manual_seed(9)
         gi, kvl, rope = model.prepare_vae_images(kvl, rope, [img_f], ident, NEW_TOKEN_IDS)
         cache = model.forward_cache_update_vae(vae, cache, **gi)
-        torch.manual_seed(9)
-        enc_noise = torch.randn(1, 16, 8, 8).to(torch.bfloat16)  # same draw as randn_like(mean) bf16? checked below
         k0 = cache.key_cache[0].clone(); vL = cache.value_cache[L - 1].clone()
-    # randn_like on a bf16 tensor draws in bf16 directly; record it precisely
+    # the reference drew randn_like(mean) with mean bf16 [1,16,8,8]; record exactly that draw
     torch.manual_seed(9)
     enc_noise = torch.randn_like(torch.empty(1, 16, 8, 8, dtype=torch.bfloat16))
     np.savez(os.path.join(OUT, "edit_prefill.npz"), **pack(dict(
         weights_sha=wdig, image=img_f, enc_noise=enc_noise, kv_lens=torch.tensor(kvl), ropes=torch.tensor(rope),
         k0=k0, vL=vL)))
+
+    # ------------------------------------------------------------------ G: host packing (prepare_* index tensors)
+    out_g = dict(weights_sha=wdig, image0=img_c0, image1=img_c1)
+
+    def put(prefix, gi):
+        for k, v in gi.items():
+            if torch.is_tensor(v):
+                out_g[prefix + k] = v.clone()
+            elif isinstance(v, list):
+                out_g[prefix + k] = torch.tensor(v)
+    kv0, rp0 = [3, 0], [2, 0]
+    gi, kv1, rp1 = model.prepare_vit_images(kv0, rp0, [img_c0, img_c1], ident, NEW_TOKEN_IDS)
+    put("vit.", gi)
+    gi, kv2, rp2 = model.prepare_prompts(kv1, rp1, prompts, tok, NEW_TOKEN_IDS)
+    put("txt.", gi)
+    img_g0, img_g1 = synth_image(64, 48, 51), synth_image(32, 32, 52)
+    out_g["vimage0"], out_g["vimage1"] = img_g0, img_g1
+    gi, kv3, rp3 = model.prepare_vae_images(kv2, rp2, [img_g0, img_g1], ident, NEW_TOKEN_IDS)
+    put("vae.", gi)
+    torch.manual_seed(77)
+    gi = model.prepare_vae_latent(kv3, rp3, [(64, 64), (32, 48)], NEW_TOKEN_IDS)
+    put("lat.", gi)
+    put("cfg.", model.prepare_vae_latent_cfg(kv1, rp1, [(64, 64), (32, 48)]))
+    put("start.", model.prepare_start_tokens(kv3, rp3, NEW_TOKEN_IDS))
+    out_g["counters"] = torch.tensor([kv1, rp1, kv2, rp2, kv3, rp3])
+    np.savez(os.path.join(OUT, "prep.npz"), **pack(out_g))
+
+    # ------------------------------------------------------------------ H: top-level InterleaveInferencer API (PIL in, str / PIL out)
+    from PIL import Image
+    import inferencer as ref_inferencer
+    from oracle.toy_tokenizer import ToyTokenizer
+    from unimedvl_amd.transforms import ImageTransform   # the reference's transform needs torchvision + cv2 (absent)
+    ttok = ToyTokenizer(NEW_TOKEN_IDS)
+    vae_tf, vit_tf = ImageTransform(64, 32, 16), ImageTransform(56, 28, 14)
+    inf = ref_inferencer.InterleaveInferencer(model, vae, ttok, vae_tf, vit_tf, NEW_TOKEN_IDS)
+    arr = ((synth_image(50, 40, 61)[0] * 0.5 + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy()
+    pil = Image.fromarray(np.stack([arr, arr, arr], -1))
+    # the reference wraps these calls in autocast("cuda") which is a no-op on CPU; supply the CPU autocast
+    with ac:
+        und = inf(image=pil, text="5 6 7 8", understanding_output=True, max_think_token_n=6)
+        torch.manual_seed(11)
+        t2i = inf(text="40 41 42", image_shapes=(64, 64), num_timesteps=4, cfg_text_scale=4.0, cfg_img_scale=1.5,
+                  cfg_interval=(0.4, 1.0), timestep_shift=3.0, cfg_renorm_type="global")
+        torch.manual_seed(12)
+        edit = inf(image=pil, text="9 10", image_shapes=(64, 48), num_timesteps=3, cfg_text_scale=4.0, cfg_img_scale=2.0,
+                   cfg_interval=(0.0, 1.0), timestep_shift=3.0, cfg_renorm_type="text_channel")
+    np.savez(os.path.join(OUT, "inferencer.npz"), **pack(dict(
+        weights_sha=wdig, pil_image=torch.from_numpy(np.asarray(pil).copy()), und_text=und["text"],
+        t2i_image=torch.from_numpy(np.asarray(t2i["image"]).copy()),
+        edit_image=torch.from_numpy(np.asarray(edit["image"]).copy()))))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(" ", f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,153 @@
+"""CPU-side checks (no GPU): host packing against the reference's own prepare_* outputs
+(bit-exact integer/index work), preprocessing helpers, the C-ABI surface, and the loud
+failure of the product path without the HIP extension / a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, NEW_TOKEN_IDS, ROOT
+
+
+class ListTokenizer:
+    def encode(self, s):
+        return [int(x) for x in s.split()]
+
+
+@pytest.fixture(scope="module")
+def prep(tiny_weights):
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.prep import BagelPrep
+    return BagelPrep(UniMedVLConfig.from_dict(tiny_weights[0]))
+
+
+def same(gi, g, prefix):
+    keys = [k[len(prefix):] for k in g if k.startswith(prefix)]
+    assert keys, prefix
+    for k in keys:
+        ref = g[prefix + k]
+        got = gi[k]
+        if isinstance(got, list):
+            got = torch.tensor(got)
+        assert got.dtype == ref.dtype or ref.dtype == torch.int64, (k, got.dtype, ref.dtype)
+        assert torch.equal(got.to(ref.dtype), ref), f"{prefix}{k} differs from the reference"
+    tensor_keys = {k for k, v in gi.items() if torch.is_tensor(v) or isinstance(v, list)}
+    assert tensor_keys == set(keys), (tensor_keys ^ set(keys))
+
+
+def test_prepare_functions_match_reference(prep):
+    g = load_golden("prep")
+    ident = lambda x: x
+    tok = ListTokenizer()
+    c = g["counters"].tolist()
+    gi, kv1, rp1 = prep.prepare_vit_images([3, 0], [2, 0], [g["image0"], g["image1"]], ident, NEW_TOKEN_IDS)
+    same(gi, g, "vit.")
+    assert [kv1, rp1] == c[0:2]
+    gi, kv2, rp2 = prep.prepare_prompts(kv1, rp1, ["5 6 7 8 9 10 11", "200 100"], tok, NEW_TOKEN_IDS)
+    same(gi, g, "txt.")
+    assert [kv2, rp2] == c[2:4]
+    gi, kv3, rp3 = prep.prepare_vae_images(kv2, rp2, [g["vimage0"], g["vimage1"]], ident, NEW_TOKEN_IDS)
+    same(gi, g, "vae.")
+    assert [kv3, rp3] == c[4:6]
+    torch.manual_seed(77)   # the reference draws the init noise from the global CPU RNG (bagel.py:835-837)
+    gi = prep.prepare_vae_latent(kv3, rp3, [(64, 64), (32, 48)], NEW_TOKEN_IDS)
+    same(gi, g, "lat.")
+    same(prep.prepare_vae_latent_cfg(kv1, rp1, [(64, 64), (32, 48)]), g, "cfg.")
+    same(prep.prepare_start_tokens(kv3, rp3, NEW_TOKEN_IDS), g, "start.")
+
+
+def test_prepare_edge_cases(prep):
+    tok = ListTokenizer()
+    gi, kv, rp = prep.prepare_prompts([0], [0], [""], tok, NEW_TOKEN_IDS)          # empty prompt -> bos, eos only
+    assert gi["packed_text_ids"].tolist() == [NEW_TOKEN_IDS["bos_token_id"], NEW_TOKEN_IDS["eos_token_id"]]
+    assert kv == [2] and rp == [2]
+    gi, kv, rp = prep.prepare_prompts([], [], [], tok, NEW_TOKEN_IDS)              # empty batch
+    assert gi["packed_text_ids"].numel() == 0 and kv == [] and rp == []
+    img = torch.zeros(3, 14, 14)                                                    # one-patch image
+    gi, kv, rp = prep.prepare_vit_images([5], [4], [img], lambda x: x, NEW_TOKEN_IDS)
+    assert gi["packed_seqlens"].tolist() == [3] and kv == [8] and rp == [5]
+    assert gi["packed_position_ids"].tolist() == [4, 4, 4]                          # an image span shares one rope position
+    with pytest.raises(AssertionError):
+        prep.prepare_vit_images([0], [0], [torch.zeros(3, 15, 14)], lambda x: x, NEW_TOKEN_IDS)
+
+
+def test_patchify_and_position_ids():
+    from unimedvl_amd.data_utils import patchify, get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate
+    img = torch.arange(3 * 28 * 42, dtype=torch.float32).reshape(3, 28, 42)
+    p = patchify(img, 14)
+    ref = torch.einsum("chpwq->hwpqc", img.reshape(3, 2, 14, 3, 14)).reshape(-1, 588)   # data_utils.py:47-49
+    assert torch.equal(p, ref)
+    assert get_flattened_position_ids_extrapolate(28, 42, 14, 70).tolist() == [0, 1, 2, 70, 71, 72]
+    ids = get_flattened_position_ids_interpolate(28, 28, 14, 4)
+    assert ids.tolist() == [0, 2, 8, 10]
+
+
+def test_transforms_and_rgb():
+    from PIL import Image
+    from unimedvl_amd.data_utils import pil_img2rgb
+    from unimedvl_amd.transforms import ImageTransform
+    tf = ImageTransform(980, 378, 14, max_pixels=2_007_040)          # data/default.yaml vlm_sft numbers
+    assert tf.resize_transform.target_size(448, 448) == (448, 448)
+    assert tf.resize_transform.target_size(2000, 1000) == (980, 490)
+    w, h = tf.resize_transform.target_size(100, 300)
+    assert w % 14 == 0 and h % 14 == 0 and max(w, h) <= 980
+    rgba = Image.new("RGBA", (20, 10), (255, 0, 0, 0))
+    out = pil_img2rgb(rgba)
+    assert out.mode == "RGB" and out.getpixel((0, 0)) == (255, 255, 255)   # transparent -> white
+    t = ImageTransform(64, 32, 16)(Image.new("L", (40, 50), 255))
+    assert t.shape[0] == 3 and t.shape[1] % 16 == 0 and t.shape[2] % 16 == 0 and float(t.max()) == 1.0
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """Every function include/unimedvl_hip.h declares must be exported by the built library and
+    bound by the ctypes layer (no compute call: this runs without a GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "unimedvl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(umv_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from unimedvl_amd import _lib
+    lib_path = _lib.LIB_PATH
+    assert os.path.exists(lib_path), "build the library first: python -m unimedvl_amd.build"
+    lib = ctypes.CDLL(lib_path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
+    assert _lib.load().umv_version() >= 100
+
+
+def test_argument_errors_come_back_through_the_abi():
+    from unimedvl_amd import _lib
+    lib = _lib.load()
+    rc = lib.umv_rmsnorm_bf16(None, None, None, None, None, 4, 64, 1e-6, None)
+    assert rc < 0 and b"null pointer" in lib.umv_last_error()
+    a = _lib.GemmArgs(x=1, ldx=8, wp=1, out=1, ldo=8, M=1, N=8, K=7, epilogue=0)
+    assert lib.umv_gemm_bf16(ctypes.byref(a), None) < 0 and b"multiples of 8" in lib.umv_last_error()
+
+
+def test_product_path_fails_loudly_without_gpu(tiny_weights):
+    if torch.cuda.is_available():
+        pytest.skip("has a GPU")
+    from unimedvl_amd import ops
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    with pytest.raises(RuntimeError):
+        Bagel(UniMedVLConfig.from_dict(tiny_weights[0]), lambda n: tiny_weights[1][n])
+    with pytest.raises(_lib_error()):
+        ops.rmsnorm(torch.zeros(2, 64, dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16), 1e-6)
+
+
+def _lib_error():
+    from unimedvl_amd._lib import UmvError
+    return UmvError
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "unimedvl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

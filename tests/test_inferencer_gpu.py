@@ -1,0 +1,90 @@
+"""Top-level drop-in API on the GPU: InterleaveInferencer.__call__ (PIL / str in, str / PIL out),
+VQAInferencer.infer_single and ImageGenerator, against outputs of the REFERENCE's own
+InterleaveInferencer run on the same PIL image, prompts, seeds and synthetic weights
+(tests/golden/inferencer.npz, oracle/gen_golden.py section H).
+Pixel tolerance: t2i (CFG amplification 4*1.5 = 6x): >= 97% of uint8 values within 6 grey levels
+and mean abs diff < 2.0; edit (4*2 = 8x amplification on every step, VAE encode + decode): >= 90%
+within 6 and mean < 3.0.  The generated image passes through 3-4 guided Euler steps and ~30-60
+bf16 VAE stages; rounding-order noise of that size also separates two CPU formulations of
+the same math (see tests/test_engine_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import load_golden, NEW_TOKEN_IDS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stack(tiny_weights):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from oracle.toy_tokenizer import ToyTokenizer
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.vae import AutoEncoder
+    cfg, sd, vae_sd, _ = tiny_weights
+    c = UniMedVLConfig.from_dict(cfg)
+    model = Bagel(c, lambda n: sd[n], device="cuda")
+    vae = AutoEncoder(c, lambda n: vae_sd[n], device="cuda")
+    return model, vae, ToyTokenizer(NEW_TOKEN_IDS)
+
+
+def pixel_close(got, ref, what, min_frac=0.97, max_mean=2.0):
+    got, ref = np.asarray(got).astype(np.int32), ref.numpy().astype(np.int32)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    d = np.abs(got - ref)
+    frac = float((d <= 6).mean())
+    assert frac >= min_frac and d.mean() < max_mean, f"{what}: {100 * frac:.2f}% within 6 levels, mean {d.mean():.3f}, max {d.max()}"
+
+
+def test_interleave_inferencer_call(stack):
+    from unimedvl_amd.inferencer import InterleaveInferencer
+    from unimedvl_amd.transforms import ImageTransform
+    model, vae, tok = stack
+    g = load_golden("inferencer")
+    pil = Image.fromarray(g["pil_image"].numpy())
+    inf = InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS)
+    assert inf() == {"image": None, "text": None}
+    und = inf(image=pil, text="5 6 7 8", understanding_output=True, max_think_token_n=6)
+    assert und["image"] is None and isinstance(und["text"], str)
+    assert und["text"] == g["und_text"], (und["text"], g["und_text"])
+    torch.manual_seed(11)
+    t2i = inf(text="40 41 42", image_shapes=(64, 64), num_timesteps=4, cfg_text_scale=4.0, cfg_img_scale=1.5,
+              cfg_interval=(0.4, 1.0), timestep_shift=3.0, cfg_renorm_type="global")
+    assert t2i["text"] is None and isinstance(t2i["image"], Image.Image)
+    pixel_close(t2i["image"], g["t2i_image"], "t2i")
+    torch.manual_seed(12)
+    edit = inf(image=pil, text="9 10", image_shapes=(64, 48), num_timesteps=3, cfg_text_scale=4.0, cfg_img_scale=2.0,
+               cfg_interval=(0.0, 1.0), timestep_shift=3.0, cfg_renorm_type="text_channel")
+    pixel_close(edit["image"], g["edit_image"], "edit", min_frac=0.90, max_mean=3.0)
+    with pytest.raises(ValueError):
+        inf(text="1", inference_ver=7)
+    with pytest.raises(ValueError):
+        inf.interleave_inference([3.14])
+
+
+def test_entry_point_classes(stack, tmp_path):
+    from unimedvl_amd.interactive_image_generator import ImageGenerator
+    from unimedvl_amd.interactive_vqa_inferencer import DEFAULT_CONFIG, VQAInferencer
+    model, vae, tok = stack
+    assert {"model_path", "target_gpu_device", "temperature", "max_new_tokens", "do_sample", "seed"} <= set(DEFAULT_CONFIG)
+    v = VQAInferencer({"max_new_tokens": 5, "do_sample": False})
+    with pytest.raises(RuntimeError):
+        v.infer_single("x.png", "1 2")
+    v.load_model(model=model, tokenizer=tok, new_token_ids=NEW_TOKEN_IDS)
+    v.image_transform = __import__("unimedvl_amd.transforms", fromlist=["ImageTransform"]).ImageTransform(56, 28, 14)
+    g = load_golden("inferencer")
+    p = tmp_path / "img.png"
+    Image.fromarray(g["pil_image"].numpy()).save(p)
+    res = v.infer_single(str(p), "5 6 7 8")
+    assert set(res) == {"answer", "input_image", "time", "image_path", "prompt", "timestamp"}
+    assert isinstance(res["answer"], str)
+    with pytest.raises(FileNotFoundError):
+        v.infer_single(str(tmp_path / "missing.png"), "1")
+    gen = ImageGenerator({"vae_transform_size": (64, 32, 16), "vit_transform_size": (56, 28, 14)})
+    gen.load_model(model=model, vae_model=vae, tokenizer=tok, new_token_ids=NEW_TOKEN_IDS)
+    out = gen.inferencer(text="40 41", image_shapes=(32, 32), num_timesteps=3)
+    assert out["image"].size == (32, 32)

@@ -22,6 +22,7 @@ from . import ops
 from .config import UniMedVLConfig
 from .data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
 from .decode import DecodeSession
+from .prep import BagelPrep
 from .kvcache import NaiveCache
 from .llm import Qwen2MoT
 from .vit import SiglipVisionModel
@@ -30,13 +31,13 @@ from .weights import GlueWeights, LLMWeights, ViTWeights
 BF16 = torch.bfloat16
 
 
-class Bagel:
+class Bagel(BagelPrep):
     def __init__(self, cfg: UniMedVLConfig, get, device="cuda", visual_gen=True, visual_und=True,
                  interpolate_pos=False):
         """`get(name)` returns reference-named tensors (see weights.py / shapes.py)."""
         if not torch.cuda.is_available():
             raise RuntimeError("unimedvl_amd needs an MI355X (ROCm) device; there is no CPU fallback")
-        self.cfg = cfg
+        BagelPrep.__init__(self, cfg, interpolate_pos)
         self.device = torch.device(device)
         self.language_model = Qwen2MoT(cfg, LLMWeights(cfg, get, self.device, load_gen=visual_gen), self.device)
         self.glue = GlueWeights(cfg, get, self.device, visual_gen, visual_und)
@@ -67,31 +68,6 @@ class Bagel:
         return self
 
     # ------------------------------------------------------------------ text
-    def prepare_prompts(self, curr_kvlens, curr_rope, prompts, tokenizer, new_token_ids):
-        text_ids, pos_ids, lens, text_idx, kv_idx = [], [], [], [], []
-        curr = 0
-        newlens, new_rope = [], []
-        for prompt, kvlen, rope in zip(prompts, curr_kvlens, curr_rope):
-            kv_idx.extend(range(curr, curr + kvlen))
-            curr += kvlen
-            ids = [new_token_ids["bos_token_id"]] + list(tokenizer.encode(prompt)) + [new_token_ids["eos_token_id"]]
-            lens.append(len(ids))
-            text_ids.extend(ids)
-            pos_ids.extend(range(rope, rope + len(ids)))
-            text_idx.extend(range(curr, curr + len(ids)))
-            newlens.append(kvlen + len(ids))
-            new_rope.append(rope + len(ids))
-            curr += len(ids)
-        generation_input = {
-            "text_token_lens": torch.tensor(lens, dtype=torch.int),
-            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
-            "packed_text_position_ids": torch.tensor(pos_ids, dtype=torch.long),
-            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
-            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
-            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
-        }
-        return generation_input, newlens, new_rope
-
     @torch.no_grad()
     def forward_cache_update_text(self, past_key_values: NaiveCache, packed_text_ids, packed_text_position_ids,
                                   text_token_lens, packed_text_indexes=None, packed_key_value_indexes=None,
@@ -105,55 +81,6 @@ class Bagel:
         return out.past_key_values
 
     # ------------------------------------------------------------------ ViT images
-    def prepare_vit_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids):
-        vit_idx, vit_lens, vit_tokens, vit_pos = [], [], [], []
-        text_ids, text_idx = [], []
-        seqlens, pos_ids, indexes, kv_idx = [], [], [], []
-        _curr = curr = 0
-        newlens, new_rope = [], []
-        for image, kvlen, rope in zip(images, curr_kvlens, curr_rope):
-            kv_idx.extend(range(curr, curr + kvlen))
-            curr += kvlen
-            text_ids.append(new_token_ids["start_of_image"])
-            text_idx.append(_curr)
-            indexes.append(curr)
-            curr += 1
-            _curr += 1
-            image_tensor = transforms(image)
-            vit_pos.append(self.get_flattened_position_ids(image_tensor.size(1), image_tensor.size(2), self.vit_patch_size,
-                                                           max_num_patches_per_side=self.vit_max_num_patch_per_side))
-            toks = patchify(image_tensor, self.vit_patch_size)
-            vit_tokens.append(toks)
-            n = toks.shape[0]
-            vit_lens.append(n)
-            vit_idx.extend(range(_curr, _curr + n))
-            indexes.extend(range(curr, curr + n))
-            curr += n
-            _curr += n
-            text_ids.append(new_token_ids["end_of_image"])
-            text_idx.append(_curr)
-            indexes.append(curr)
-            curr += 1
-            _curr += 1
-            pos_ids.extend([rope] * (n + 2))
-            seqlens.append(n + 2)
-            newlens.append(kvlen + n + 2)
-            new_rope.append(rope + 1)
-        generation_input = {
-            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
-            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
-            "vit_token_seqlens": torch.tensor(vit_lens, dtype=torch.int),
-            "packed_vit_tokens": torch.cat(vit_tokens, dim=0),
-            "packed_vit_position_ids": torch.cat(vit_pos, dim=0),
-            "packed_vit_token_indexes": torch.tensor(vit_idx, dtype=torch.long),
-            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
-            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
-            "packed_indexes": torch.tensor(indexes, dtype=torch.long),
-            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
-            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
-        }
-        return generation_input, newlens, new_rope
-
     def encode_vit(self, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens):
         """ViT tower + connector + vit_pos_embed (bagel.py:581-592); returns [N, hidden] bf16 (pre-scatter)."""
         lens = vit_token_seqlens.to("cpu")
@@ -184,64 +111,6 @@ class Bagel:
         return out.past_key_values
 
     # ------------------------------------------------------------------ VAE-encoded images (edit / reconstruction)
-    def prepare_vae_images(self, curr_kvlens, curr_rope, images, transforms, new_token_ids, timestep=0):
-        shapes, vae_pos, vae_idx = [], [], []
-        text_ids, text_idx = [], []
-        seqlens, pos_ids, indexes, kv_idx = [], [], [], []
-        _curr = curr = 0
-        tensors = []
-        newlens, new_rope = [], []
-        for image, kvlen, rope in zip(images, curr_kvlens, curr_rope):
-            kv_idx.extend(range(curr, curr + kvlen))
-            curr += kvlen
-            text_ids.append(new_token_ids["start_of_image"])
-            text_idx.append(_curr)
-            indexes.append(curr)
-            curr += 1
-            _curr += 1
-            image_tensor = transforms(image)
-            tensors.append(image_tensor)
-            vae_pos.append(self.get_flattened_position_ids(image_tensor.size(1), image_tensor.size(2),
-                                                           self.latent_downsample,
-                                                           max_num_patches_per_side=self.max_latent_size))
-            H, W = image_tensor.shape[1:]
-            h, w = H // self.latent_downsample, W // self.latent_downsample
-            shapes.append((h, w))
-            n = h * w
-            vae_idx.extend(range(_curr, _curr + n))
-            indexes.extend(range(curr, curr + n))
-            curr += n
-            _curr += n
-            text_ids.append(new_token_ids["end_of_image"])
-            text_idx.append(_curr)
-            indexes.append(curr)
-            curr += 1
-            _curr += 1
-            pos_ids.extend([rope] * (n + 2))
-            seqlens.append(n + 2)
-            newlens.append(kvlen + n + 2)
-            new_rope.append(rope + 1)
-        sizes = [t.shape for t in tensors]
-        max_size = [max(s) for s in zip(*sizes)]
-        padded = torch.zeros(size=(len(tensors), *max_size))
-        for i, t in enumerate(tensors):
-            padded[i, :, :t.shape[1], :t.shape[2]] = t
-        generation_input = {
-            "padded_images": padded,
-            "patchified_vae_latent_shapes": shapes,
-            "packed_vae_position_ids": torch.cat(vae_pos, dim=0),
-            "packed_timesteps": torch.tensor([timestep]),
-            "packed_vae_token_indexes": torch.tensor(vae_idx, dtype=torch.long),
-            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
-            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
-            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
-            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
-            "packed_indexes": torch.tensor(indexes, dtype=torch.long),
-            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
-            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
-        }
-        return generation_input, newlens, new_rope
-
     def time_embed(self, t_values):
         """TimestepEmbedder (modeling_utils.py:87-109) for a vector of timesteps -> [n, hidden] bf16.
         The 256-wide sinusoid is built on the host in fp32 with torch (same bits as the
@@ -280,65 +149,6 @@ class Bagel:
         return out.past_key_values
 
     # ------------------------------------------------------------------ image generation
-    def prepare_vae_latent(self, curr_kvlens, curr_rope, image_sizes, new_token_ids):
-        text_ids, text_idx = [], []
-        vae_pos, vae_idx, noises = [], [], []
-        pos_ids, seqlens, indexes, kv_idx = [], [], [], []
-        query_curr = curr = 0
-        for (H, W), kvlen, rope in zip(image_sizes, curr_kvlens, curr_rope):
-            kv_idx.extend(range(curr, curr + kvlen))
-            curr += kvlen
-            text_ids.append(new_token_ids["start_of_image"])
-            text_idx.append(query_curr)
-            indexes.append(curr)
-            curr += 1
-            query_curr += 1
-            vae_pos.append(self.get_flattened_position_ids(H, W, self.latent_downsample,
-                                                           max_num_patches_per_side=self.max_latent_size))
-            h, w = H // self.latent_downsample, W // self.latent_downsample
-            n = h * w
-            noises.append(torch.randn(n, self.latent_channel * self.latent_patch_size ** 2))   # CPU RNG, as the reference
-            vae_idx.extend(range(query_curr, query_curr + n))
-            indexes.extend(range(curr, curr + n))
-            curr += n
-            query_curr += n
-            text_ids.append(new_token_ids["end_of_image"])
-            text_idx.append(query_curr)
-            indexes.append(curr)
-            curr += 1
-            query_curr += 1
-            pos_ids.extend([rope] * (n + 2))
-            seqlens.append(n + 2)
-        return {
-            "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
-            "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
-            "packed_init_noises": torch.cat(noises, dim=0),
-            "packed_vae_position_ids": torch.cat(vae_pos, dim=0),
-            "packed_vae_token_indexes": torch.tensor(vae_idx, dtype=torch.long),
-            "packed_seqlens": torch.tensor(seqlens, dtype=torch.int),
-            "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
-            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
-            "packed_indexes": torch.tensor(indexes, dtype=torch.long),
-            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
-        }
-
-    def prepare_vae_latent_cfg(self, curr_kvlens, curr_rope, image_sizes):
-        pos_ids, indexes, kv_idx = [], [], []
-        curr = 0
-        for (H, W), kvlen, rope in zip(image_sizes, curr_kvlens, curr_rope):
-            kv_idx.extend(range(curr, curr + kvlen))
-            curr += kvlen
-            n = (H // self.latent_downsample) * (W // self.latent_downsample)
-            indexes.extend(range(curr, curr + n + 2))
-            curr += n + 2
-            pos_ids.extend([rope] * (n + 2))
-        return {
-            "cfg_packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),
-            "cfg_key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
-            "cfg_packed_query_indexes": torch.tensor(indexes, dtype=torch.long),
-            "cfg_packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
-        }
-
     @torch.no_grad()
     def generate_image(self, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
                        packed_vae_token_indexes, packed_seqlens, packed_position_ids, packed_indexes=None,
@@ -406,21 +216,6 @@ class Bagel:
         return x_t.split([n - 2 for n in seqlens])
 
     # ------------------------------------------------------------------ text generation
-    def prepare_start_tokens(self, curr_kvlens, curr_rope, new_token_ids):
-        start, kv_idx, pos = [], [], []
-        curr = 0
-        for kvlen, rope in zip(curr_kvlens, curr_rope):
-            kv_idx.extend(range(curr, curr + kvlen))
-            start.append(new_token_ids["bos_token_id"])
-            pos.append(rope)
-            curr += kvlen
-        return {
-            "packed_start_tokens": torch.tensor(start, dtype=torch.long),
-            "packed_query_position_ids": torch.tensor(pos, dtype=torch.long),
-            "key_values_lens": torch.tensor(list(curr_kvlens), dtype=torch.int),
-            "packed_key_value_indexes": torch.tensor(kv_idx, dtype=torch.long),
-        }
-
     @torch.no_grad()
     def generate_text(self, past_key_values: NaiveCache, packed_key_value_indexes=None, key_values_lens=None,
                       packed_start_tokens=None, packed_query_position_ids=None, max_length: int = 0,

@@ -1,0 +1,107 @@
+"""Image generation / editing entry point - importable counterpart of the reference's
+notebook-style script (codes/interactive_image_generator.py:56-275): same ``DEFAULT_CONFIG``
+keys, ``ImageGenerator(config).load_model()`` building ``.inferencer`` (an
+InterleaveInferencer), ``.set_seed``.  The example cell (understand-then-edit,
+interactive_image_generator.py:290-397) is ``edit_with_understanding``.
+"""
+import os
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from .bagel import Bagel
+from .checkpoint import SafetensorsGetter, find_weights_file, vae_getter
+from .config import UniMedVLConfig
+from .data_utils import add_special_tokens
+from .inferencer import InterleaveInferencer
+from .shapes import all_shapes
+from .transforms import ImageTransform
+from .vae import AutoEncoder
+
+DEFAULT_CONFIG = {
+    "model_path": "/path/to/unimedvl_checkpoint",
+    "target_gpu_device": "0",
+    "max_mem_per_gpu": "40GiB",
+    "enable_cpu_loading": True,
+    "use_model_checkpoint": False,
+    "enable_auto_bf16_conversion": True,
+    "offload_folder": "/tmp/bagel_offload",
+    "seed": 42,
+    "vae_transform_size": (1024, 32, 16),
+    "vit_transform_size": (980, 387, 14),
+    "text_do_sample": False,
+    "text_temperature": 0.3,
+}
+
+
+class ImageGenerator:
+    def __init__(self, config: Optional[Dict[str, Any]] = None):
+        self.config = dict(DEFAULT_CONFIG)
+        if config:
+            self.config.update(config)
+        self.model = self.vae_model = self.tokenizer = None
+        self.vae_transform = self.vit_transform = None
+        self.new_token_ids = None
+        self.inferencer = None
+        self.loaded = False
+
+    def set_seed(self, seed):
+        import random
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+
+    def load_model(self, model=None, vae_model=None, tokenizer=None, new_token_ids=None):
+        if self.loaded:
+            print("Model already loaded")
+            return
+        self.set_seed(self.config["seed"])
+        if model is None:
+            model_path = self.config.get("model_path")
+            if not model_path:
+                raise ValueError("model_path required")
+            cfg = UniMedVLConfig.from_checkpoint_dir(model_path, max_latent_size=64, vit_max_num_patch_per_side=70)
+            device = f"cuda:{self.config['target_gpu_device']}"
+            get = SafetensorsGetter(find_weights_file(model_path, self.config["use_model_checkpoint"]), all_shapes(cfg))
+            model = Bagel(cfg, get, device=device, visual_gen=True, visual_und=True)
+            vae_model = AutoEncoder(cfg, vae_getter(os.path.join(model_path, "ae.safetensors")), device=device)
+            from .interactive_vqa_inferencer import load_tokenizer
+            tokenizer, new_token_ids, _ = add_special_tokens(load_tokenizer(model_path))
+        self.model, self.vae_model, self.tokenizer, self.new_token_ids = model, vae_model, tokenizer, new_token_ids
+        self.vae_transform = ImageTransform(*self.config["vae_transform_size"])
+        self.vit_transform = ImageTransform(*self.config["vit_transform_size"])
+        self.inferencer = InterleaveInferencer(model=self.model, vae_model=self.vae_model, tokenizer=self.tokenizer,
+                                               vae_transform=self.vae_transform, vit_transform=self.vit_transform,
+                                               new_token_ids=self.new_token_ids)
+        self.loaded = True
+
+    def show_gpu_memory(self):
+        if torch.cuda.is_available():
+            for i in range(torch.cuda.device_count()):
+                allocated = torch.cuda.memory_allocated(i) / 1024 ** 3
+                total = torch.cuda.get_device_properties(i).total_memory / 1024 ** 3
+                print(f"GPU {i}: {allocated:.1f}GB / {total:.1f}GB ({allocated / total * 100:.1f}%)")
+
+    def edit_with_understanding(self, image, edit_instruction, use_thinking=False, seed=None, cfg_text_scale=4.0,
+                                cfg_img_scale=2.0, cfg_interval=(0.0, 1.0), timestep_shift=3.0, num_timesteps=50,
+                                cfg_renorm_min=0.0, cfg_renorm_type="text_channel", max_think_token_n=1024):
+        """The script's cell 4: describe the image, then edit it conditioned on image + text
+        (interactive_image_generator.py:290-397)."""
+        if not self.loaded:
+            raise RuntimeError("Model not loaded, please call load_model() first")
+        if seed is not None:
+            self.set_seed(seed)
+        understanding = self.inferencer(image=image, text=edit_instruction, understanding_output=True,
+                                        think=use_thinking, do_sample=self.config["text_do_sample"],
+                                        text_temperature=self.config["text_temperature"],
+                                        max_think_token_n=max_think_token_n)
+        h, w = self.inferencer._calculate_target_size_with_aspect_ratio(*image.size)
+        edited = self.inferencer(image=image, text=edit_instruction, think=use_thinking, cfg_text_scale=cfg_text_scale,
+                                 cfg_img_scale=cfg_img_scale, cfg_interval=list(cfg_interval), timestep_shift=timestep_shift,
+                                 num_timesteps=num_timesteps, cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type,
+                                 image_shapes=(h, w), do_sample=self.config["text_do_sample"],
+                                 text_temperature=self.config["text_temperature"])
+        return {"understanding": understanding["text"], "image": edited["image"], "text": edited["text"]}
