@@ -68,6 +68,10 @@ typedef struct {
                                  qwen2_navit.py:552-562,619-620,891-898) */
     int M, N, K;
     int epilogue;
+    const uint16_t* norm_w;   /* optional [K]: fuse Qwen2RMSNorm(x) * norm_w into the prologue (decode path,
+                                 qwen2_navit.py:861,888,1164 feeding :541-543, modeling_qwen2.py:234, bagel.py:1295);
+                                 needs M <= 16 and K <= 4096 */
+    float norm_eps;
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 

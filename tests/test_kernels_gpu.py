@@ -98,6 +98,27 @@ def test_gemm_epilogues(ops, M):
     assert_close_bf16(outbuf, ref, what="row_idx")
 
 
+@pytest.mark.parametrize("M,N,K,swiglu", [(8, 4608, 3584, False), (8, 37888, 3584, True), (3, 320, 256, False),
+                                          (16, 512, 1152, False), (11, 2048, 4096, True), (1, 64, 32, False)])
+def test_gemm_fused_rmsnorm(ops, M, N, K, swiglu):
+    """decode path: Qwen2RMSNorm folded into the skinny GEMM prologue == rmsnorm kernel then GEMM."""
+    from oracle.unimedvl_cpu import rmsnorm
+    x, nw = rnd((M, K), 60, 1.5), (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(61))).to(BF16)
+    xn = rmsnorm(x, nw, 1e-6)
+    if swiglu:
+        wg, wu = rnd((N // 2, K), 62, 1 / math.sqrt(K)), rnd((N // 2, K), 63, 1 / math.sqrt(K))
+        lin = ops.PackedLinear.from_gate_up(wg.cuda(), wu.cuda())
+        ref = F.silu((xn.float() @ wg.float().T).to(BF16)) * (xn.float() @ wu.float().T).to(BF16)
+    else:
+        w, b = rnd((N, K), 64, 1 / math.sqrt(K)), rnd((N,), 65)
+        lin = ops.PackedLinear.from_weight(w.cuda(), b.cuda())
+        ref = (xn.float() @ w.float().T + b.float()).to(BF16)
+    out = ops.gemm(x.cuda(), lin, norm_w=nw.cuda(), norm_eps=1e-6)
+    two_step = ops.gemm(ops.rmsnorm(x.cuda(), nw.cuda(), 1e-6), lin)
+    assert_close_bf16(out, ref, what=f"fused norm gemm {M}x{N}x{K}", frac_exact=0.97)
+    assert_close_bf16(out, two_step.cpu(), what="fused vs two-step", frac_exact=0.97)
+
+
 def test_norms(ops):
     from oracle.unimedvl_cpu import rmsnorm
     for T, H in [(8, 3584), (5, 256), (300, 128), (1000, 1152)]:

@@ -19,6 +19,7 @@ class GemmArgs(C.Structure):
         ("x", C.c_void_p), ("ldx", C.c_int64), ("wp", C.c_void_p), ("bias", C.c_void_p),
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
         ("row_idx", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
+        ("norm_w", C.c_void_p), ("norm_eps", C.c_float),
     ]
 
 

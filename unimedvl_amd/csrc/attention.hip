@@ -75,19 +75,53 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
+    // K fragments of a 32-key block; A row i=(lane&15) of tile t  <->  key kb + (i>>2)*8 + t*4 + (i&3)
+    constexpr bool PREFETCH = HD <= 128;   // register budget: K(next) + V(cur) in flight while S/softmax run
+    auto load_k = [&](int kb, bf16x8 (&kf)[2][PREFETCH ? KS : 1]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
+            const bf16_t* kp = kbase + (int64_t)key * HD;
+#pragma unroll
+            for (int ks = 0; ks < (PREFETCH ? KS : 1); ++ks) {
+                const int d = ks * 32 + g * 8;
+                kf[t][ks] = (d < HD) ? ldg_frag(kp + d) : zero_frag();
+            }
+        }
+    };
+    constexpr int KSP = PREFETCH ? KS : 1, DTP = PREFETCH ? DT : 1;
+    bf16x8 kcur[2][KSP], knext[2][KSP];
+    if constexpr (PREFETCH) {
+        if (kb_begin < kb_end) load_k(kb_begin, kcur);
+    }
     for (int kb = kb_begin; kb < kb_end; kb += 32) {
-        // ---- S^T = K Q^T; A row i=(lane&15) of tile t  <->  key kb + (i>>2)*8 + t*4 + (i&3)
+        // issue this block's V^T loads and the next block's K loads before any math
+        bf16x8 vf[DTP];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + j;
+                vf[dt] = (d < HD) ? ldg_frag(vbase + (int64_t)d * a.v_d_stride + kb + g * 8) : zero_frag();
+            }
+            if (kb + 32 < kb_end) load_k(kb + 32, knext);
+        }
+        // ---- S^T = K Q^T
         f32x4 st[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-            const bf16_t* kp = kbase + (int64_t)key * HD;
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int d = ks * 32 + g * 8;
-                bf16x8 kf = (d < HD) ? ldg_frag(kp + d) : zero_frag();
-                st[t] = mfma16(kf, qf[ks], st[t]);
+                for (int ks = 0; ks < KS; ++ks) st[t] = mfma16(kcur[t][ks], qf[ks], st[t]);
+            } else {   // large head_dim: stream the K fragments through the MFMA chain
+                const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
+                const bf16_t* kp = kbase + (int64_t)key * HD;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d = ks * 32 + g * 8;
+                    bf16x8 kf = (d < HD) ? ldg_frag(kp + d) : zero_frag();
+                    st[t] = mfma16(kf, qf[ks], st[t]);
+                }
             }
         }
         // lane (row j, g) now holds scores of keys kb + g*8 + t*4 + r
@@ -126,12 +160,25 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
         const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const int d = dt * 16 + j;
-            bf16x8 vf = (d < HD) ? ldg_frag(vbase + (int64_t)d * a.v_d_stride + kb + g * 8) : zero_frag();
-            if (partial) vf = mask_keys(vf, nvalid);
+            bf16x8 v;
+            if constexpr (PREFETCH) {
+                v = vf[dt];
+            } else {
+                const int d = dt * 16 + j;
+                v = (d < HD) ? ldg_frag(vbase + (int64_t)d * a.v_d_stride + kb + g * 8) : zero_frag();
+            }
+            if (partial) v = mask_keys(v, nvalid);
             f32x4 acc = o[dt];
             acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
-            o[dt] = mfma16(vf, pf, acc);
+            o[dt] = mfma16(v, pf, acc);
+        }
+        if constexpr (PREFETCH) {
+            if (kb + 32 < kb_end) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kcur[t][ks] = knext[t][ks];
+            }
         }
     }
     if (!rvalid) return;
@@ -162,34 +209,46 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     }
 }
 
-template <int HD>
+// Merge the nsplit partial (O, m, l) triples of one (token, head) row.  One wavefront per row; the
+// (m, l) pairs are read by lanes 0..nsplit-1 in one go and the weighted O sums use independent,
+// fully unrolled loads (the kernel is pure latency otherwise).
+template <int HD, int MAXS>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
                                                            const int32_t* __restrict__ cu_q, int nseg, int nq, int nsplit) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (tok*nq + head)
     if (row >= (int64_t)cu_q[nseg] * nq) return;
     const float* base = ws + row * nsplit * (HD + 4);
-    float M = -INFINITY;
-    for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, base[sidx * (HD + 4) + HD]);
-    float L = 0.f;
-    float acc[(HD + 63) / 64];
+    float m = -INFINITY, l = 0.f;
+    if (lane < nsplit) {
+        m = base[lane * (HD + 4) + HD];
+        l = base[lane * (HD + 4) + HD + 1];
+    }
+    const float M = wave_max(m);
+    const float wgt = (m == -INFINITY) ? 0.f : exp2f(m - M);
+    const float L = wave_sum(wgt * l);
+    constexpr int PER = (HD + 63) / 64;
+    float acc[PER];
 #pragma unroll
-    for (int i = 0; i < (HD + 63) / 64; ++i) acc[i] = 0.f;
-    for (int sidx = 0; sidx < nsplit; ++sidx) {
-        const float* p = base + sidx * (HD + 4);
-        const float m = p[HD], l = p[HD + 1];
-        const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
-        L += w * l;
+    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
+    float vals[MAXS][PER];
 #pragma unroll
-        for (int i = 0; i < (HD + 63) / 64; ++i) {
-            int d = i * 64 + lane;
-            if (d < HD && w > 0.f) acc[i] += w * p[d];
+    for (int sidx = 0; sidx < MAXS; ++sidx)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int d = i * 64 + lane;
+            vals[sidx][i] = (sidx < nsplit && d < HD) ? base[sidx * (HD + 4) + d] : 0.f;
         }
+#pragma unroll
+    for (int sidx = 0; sidx < MAXS; ++sidx) {
+        const float w = __shfl(wgt, sidx, 64);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] += w * vals[sidx][i];
     }
     const float inv = L > 0.f ? 1.0f / L : 0.f;
 #pragma unroll
-    for (int i = 0; i < (HD + 63) / 64; ++i) {
-        int d = i * 64 + lane;
+    for (int i = 0; i < PER; ++i) {
+        const int d = i * 64 + lane;
         if (d < HD) out[row * HD + d] = f2bf(acc[i] * inv);
     }
 }
@@ -204,7 +263,7 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     const umv_attn_args& a = *ap;
     UMV_CHECK(a.q && a.out && a.cu_q && a.kv_len && a.k_slab && a.vt_slab, UMV_ERR_ARG, "attn: null pointer");
     UMV_CHECK(a.nkv > 0 && a.nq % a.nkv == 0 && a.nq / a.nkv <= 16, UMV_ERR_ARG, "attn: bad head counts nq=%d nkv=%d", a.nq, a.nkv);
-    UMV_CHECK(a.nsplit >= 1 && (a.nsplit == 1 || a.workspace), UMV_ERR_ARG, "attn: nsplit=%d needs workspace", a.nsplit);
+    UMV_CHECK(a.nsplit >= 1 && a.nsplit <= 32 && (a.nsplit == 1 || a.workspace), UMV_ERR_ARG, "attn: nsplit=%d (1..32) needs workspace", a.nsplit);
     UMV_CHECK((a.v_d_stride % 8) == 0, UMV_ERR_ARG, "attn: slab capacity must be a multiple of 8");
     if (a.nseg == 0 || a.max_q == 0) return UMV_OK;
     const int G = a.nq / a.nkv;
@@ -226,10 +285,10 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
         // grid over the static bound nseg*max_q tokens; rows beyond cu_q[nseg]*nq exit on device
         int64_t rows = (int64_t)a.nseg * a.max_q * a.nq;
         if (a.hd == 128)
-            hipLaunchKernelGGL((attn_combine_kernel<128>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+            hipLaunchKernelGGL((attn_combine_kernel<128, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                                (const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.nsplit);
         else
-            hipLaunchKernelGGL((attn_combine_kernel<72>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+            hipLaunchKernelGGL((attn_combine_kernel<72, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                                (const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.nsplit);
         UMV_LAUNCH_CHECK();
     }

@@ -61,14 +61,65 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
 }
 
+// Few rows (decode): latency bound, so one 256-thread workgroup per row with the x AND weight
+// loads issued together up front (one memory round trip) and a single LDS exchange.
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_rowblock_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                               const bf16_t* __restrict__ wg, const int32_t* __restrict__ expert,
+                                                               bf16_t* __restrict__ out, int H, float eps) {
+    __shared__ float part[4];
+    const int row = blockIdx.x;
+    const bf16_t* xr = x + (int64_t)row * H;
+    const bf16_t* wr = (expert && expert[row]) ? wg : w;
+    const int nv = H / 8;
+    bf16x8 v[MAXV], ww[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + threadIdx.x;
+        v[i] = c < nv ? ldg_frag(xr + c * 8) : zero_frag();
+        ww[i] = c < nv ? ldg_frag(wr + c * 8) : zero_frag();
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = bf2f((bf16_t)v[i][j]);
+            ss += f * f;
+        }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    const float rstd = rsqrt_ieee(tot / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + threadIdx.x;
+        if (c < nv) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bf2f((bf16_t)ww[i][j]) * rbf(bf2f((bf16_t)v[i][j]) * rstd));
+            *reinterpret_cast<bf16x8*>(out + (int64_t)row * H + c * 8) = o;
+        }
+    }
+}
+
 extern "C" int umv_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* w_gen, const int32_t* expert,
                                 uint16_t* out, int T, int H, float eps, umv_stream_t stream) {
     UMV_CHECK(x && w && out, UMV_ERR_ARG, "rmsnorm: null pointer");
     UMV_CHECK(H % 8 == 0 && H <= 64 * 8 * 16, UMV_ERR_ARG, "rmsnorm: H=%d unsupported", H);
     UMV_CHECK(!expert || w_gen, UMV_ERR_ARG, "rmsnorm: expert routing without w_gen");
     if (T == 0) return UMV_OK;
-    dim3 grid((T + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (T <= 64 && H >= 1024) {
+        if (H <= 256 * 8 * 2)
+            hipLaunchKernelGGL((rmsnorm_rowblock_kernel<2>), dim3(T), dim3(256), 0, s, x, w, w_gen, expert, out, H, eps);
+        else
+            hipLaunchKernelGGL((rmsnorm_rowblock_kernel<4>), dim3(T), dim3(256), 0, s, x, w, w_gen, expert, out, H, eps);
+        UMV_LAUNCH_CHECK();
+        return UMV_OK;
+    }
+    dim3 grid((T + 3) / 4), block(256);
     if (H <= 512 * 2)
         hipLaunchKernelGGL((rmsnorm_kernel<2>), grid, block, 0, s, x, w, w_gen, expert, out, T, H, eps);
     else if (H <= 512 * 8)

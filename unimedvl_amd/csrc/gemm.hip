@@ -167,10 +167,25 @@ __device__ __forceinline__ void epi_swiglu4(const EpiCtx& e, int64_t orow, int c
 }
 
 // ----------------------------------------------------------------------------- skinny (M <= 64)
+// Weight streaming, HBM-bound.  One workgroup = NT n-tiles x all of K; its 8 waves take
+// contiguous K slices and reduce through LDS.  Each wave keeps U weight fragments per n-tile
+// in flight (U KiB of contiguous HBM per n-tile) and, when DB, prefetches the next chunk
+// while the MFMAs of the current one issue.  NORM fuses Qwen2RMSNorm (modeling_qwen2.py:89-94)
+// of the x rows into the prologue: the wave holds its whole K slice of x in registers,
+// the row sum of squares is combined across waves through LDS, and the fragments are
+// normalised in place with the reference's two bf16 roundings before feeding the MFMAs.
 #define SK_WAVES 8
-template <int MB, int NT>
+#define SK_XMAX 16   // NORM: k-tiles of x a wave can hold (K <= 8*16*32 = 4096)
+
+template <int MB, int NT, int U>
+struct SkBuf {
+    bf16x8 w[U][NT];
+    bf16x8 x[U][MB];
+};
+
+template <int MB, int NT, int U, bool DB, bool NORM>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_args a, int KT, int NTT) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [SK_WAVES][NT*MB*4][64]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [SK_WAVES][NT*MB*4][64] (+ norm partials)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -194,26 +209,130 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
     const int kt_per = (KT + SK_WAVES - 1) / SK_WAVES;
     const int kt_begin = wave * kt_per;
     const int kt_end = min(KT, kt_begin + kt_per);
+    const int nk = max(0, kt_end - kt_begin);
+    const int nchunks = (nk + U - 1) / U;
     const bf16_t* wbase[NT];
-    bool tvalid[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        tvalid[t] = (nt0 + t) < NTT;
-        wbase[t] = a.wp + ((int64_t)(tvalid[t] ? nt0 + t : 0) * KT) * 512 + lane * 8;
+        const bool tv = (nt0 + t) < NTT;
+        wbase[t] = a.wp + ((int64_t)(tv ? nt0 + t : 0) * KT) * 512 + lane * 8;
     }
-#pragma unroll 4
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int k = kt * 32 + g * 8;
-        bf16x8 wf[NT];
+    auto load_chunk = [&](int c, SkBuf<MB, NT, U>& b) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wbase[t] + (int64_t)kt * 512));
-        bf16x8 xf[MB];
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt_begin + c * U + u;
+            const bool ok = kt < kt_end;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) xf[mb] = (xvalid[mb] && k < a.K) ? ldg_frag(xrow[mb] + k) : zero_frag();
+            for (int t = 0; t < NT; ++t)
+                b.w[u][t] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wbase[t] + (int64_t)kt * 512)) : zero_frag();
+            if (!NORM) {
+                const int k = kt * 32 + g * 8;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+                for (int mb = 0; mb < MB; ++mb) b.x[u][mb] = (ok && xvalid[mb] && k < a.K) ? ldg_frag(xrow[mb] + k) : zero_frag();
+            }
+        }
+    };
+    SkBuf<MB, NT, U> b0, b1;
+    if (nchunks > 0) load_chunk(0, b0);
+
+    if constexpr (NORM) {
+        static_assert(!NORM || MB == 1, "fused RMSNorm supports M <= 16");
+        // Stage RMSNorm(x) * norm_w ONCE per workgroup into LDS, already in MFMA B-fragment order:
+        // slot (kt, g, r) holds the 8 bf16 of row r at k = kt*32 + g*8.  MP = rows kept (8 or 16).
+        const int MP = a.M <= 8 ? 8 : 16;
+        bf16_t* xl = reinterpret_cast<bf16_t*>(red + SK_WAVES * NT * MB * 4 * 64 + SK_WAVES * 16);
+        float* part = red + SK_WAVES * NT * MB * 4 * 64;   // [SK_WAVES][16]
+        const int rr = tid & (MP - 1);
+        const int per_kt = 4 * MP;
+        const int nslots = KT * per_kt;
+        const bool rowok = rr < a.M;
+        const bf16_t* xr = a.x + (rowok ? (a.row_idx ? (int64_t)a.row_idx[rr] : (int64_t)rr) : 0) * a.ldx;
+        // pass 1: row sums of squares (x is tiny and L2 resident; it is re-read in pass 2 rather than
+        // held in registers, which keeps the kernel at 2 workgroups per CU)
+        float ss = 0.f;
+        for (int sidx = tid; sidx < nslots; sidx += SK_WAVES * 64) {
+            const int kt = sidx / per_kt, gg = (sidx % per_kt) / MP;
+            const int k = kt * 32 + gg * 8;
+            if (rowok && k < a.K) {
+                bf16x8 v = ldg_frag(xr + k);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(wf[t], xf[mb], acc[t][mb]);
+                for (int j = 0; j < 8; ++j) {
+                    float f = bf2f((bf16_t)v[j]);
+                    ss += f * f;
+                }
+            }
+        }
+        // lanes sharing a row: lane & (MP-1)
+        if (MP == 8) ss += __shfl_xor(ss, 8, 64);
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < MP) part[wave * 16 + lane] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) tot += part[w * 16 + rr];
+        const float rstd = rsqrt_ieee(tot / (float)a.K + a.norm_eps);
+        // pass 2: normalise with the reference's two bf16 roundings and store fragments
+        for (int sidx = tid; sidx < nslots; sidx += SK_WAVES * 64) {
+            const int kt = sidx / per_kt, gg = (sidx % per_kt) / MP;
+            const int k = kt * 32 + gg * 8;
+            bf16x8 o = zero_frag();
+            if (rowok && k < a.K) {
+                bf16x8 v = ldg_frag(xr + k);
+                bf16x8 wn = ldg_frag(a.norm_w + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bf2f((bf16_t)wn[j]) * rbf(bf2f((bf16_t)v[j]) * rstd));
+            }
+            *reinterpret_cast<bf16x8*>(xl + (int64_t)sidx * 8) = o;
+        }
+        __syncthreads();
+        const int rsel = r & (MP - 1);
+        auto xfrag = [&](int kt) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(xl + ((int64_t)(kt * 4 + g) * MP + rsel) * 8);
+        };
+        for (int c = 0; c < nchunks; c += 2) {
+            if (DB && c + 1 < nchunks) load_chunk(c + 1, b1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kt = min(kt_begin + c * U + u, KT - 1);
+                bf16x8 xf = xfrag(kt);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t][0] = mfma16(b0.w[u][t], xf, acc[t][0]);
+            }
+            if (c + 1 < nchunks) {
+                if (!DB) load_chunk(c + 1, b1);
+                if (c + 2 < nchunks && DB) load_chunk(c + 2, b0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kt = min(kt_begin + (c + 1) * U + u, KT - 1);
+                    bf16x8 xf = xfrag(kt);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t][0] = mfma16(b1.w[u][t], xf, acc[t][0]);
+                }
+                if (c + 2 < nchunks && !DB) load_chunk(c + 2, b0);
+            }
+        }
+    } else {
+        for (int c = 0; c < nchunks; c += 2) {
+            if (DB && c + 1 < nchunks) load_chunk(c + 1, b1);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(b0.w[u][t], b0.x[u][mb], acc[t][mb]);
+            if (c + 1 < nchunks) {
+                if (!DB) load_chunk(c + 1, b1);
+                if (c + 2 < nchunks && DB) load_chunk(c + 2, b0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(b1.w[u][t], b1.x[u][mb], acc[t][mb]);
+                if (c + 2 < nchunks && !DB) load_chunk(c + 2, b0);
+            }
+        }
     }
     // cross-wave reduction through LDS
     constexpr int E4 = NT * MB;  // f32x4 fragments per lane
@@ -378,11 +497,12 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(umv_gemm_args a, int KT
     }
 }
 
-template <int MB, int NT>
+template <int MB, int NT, int U, bool DB, bool NORM>
 static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     int blocks = (NTT + NT - 1) / NT;
     size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT, NTT);
+    if (NORM) lds += SK_WAVES * 16 * sizeof(float) + (size_t)KT * 4 * (a.M <= 8 ? 8 : 16) * 16;
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT, NTT);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -397,15 +517,20 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(!(a.epilogue & UMV_EPI_BIAS) || a.bias, UMV_ERR_ARG, "gemm: BIAS without bias pointer");
     UMV_CHECK(!(a.epilogue & UMV_EPI_RESIDUAL) || a.residual, UMV_ERR_ARG, "gemm: RESIDUAL without residual pointer");
     UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm: SWIGLU needs N %% 32 == 0");
+    UMV_CHECK(!a.norm_w || (a.M <= 16 && a.K <= SK_WAVES * SK_XMAX * 32), UMV_ERR_UNSUPPORTED,
+              "gemm: fused RMSNorm needs M <= 16 and K <= %d (got M=%d K=%d)", SK_WAVES * SK_XMAX * 32, a.M, a.K);
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 31) / 32;
     const int NTT = (a.N + 15) / 16;
     if (a.M <= 64) {
         const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
-        if (a.M <= 16) return two ? launch_skinny<1, 2>(a, KT, NTT, s) : launch_skinny<1, 1>(a, KT, NTT, s);
-        if (a.M <= 32) return two ? launch_skinny<2, 2>(a, KT, NTT, s) : launch_skinny<2, 1>(a, KT, NTT, s);
-        return two ? launch_skinny<4, 2>(a, KT, NTT, s) : launch_skinny<4, 1>(a, KT, NTT, s);
+        if (a.M <= 16) {
+            if (a.norm_w) return two ? launch_skinny<1, 2, 4, true, true>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, true>(a, KT, NTT, s);
+            return two ? launch_skinny<1, 2, 4, true, false>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, false>(a, KT, NTT, s);
+        }
+        if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, false>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, false>(a, KT, NTT, s);
+        return two ? launch_skinny<4, 2, 2, false, false>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, false>(a, KT, NTT, s);
     }
     int mblocks = (a.M + TG_BM - 1) / TG_BM;
     int nblocks = (a.N + TG_BN - 1) / TG_BN;

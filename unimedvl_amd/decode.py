@@ -17,7 +17,8 @@ BF16 = torch.bfloat16
 
 
 class DecodeSession:
-    def __init__(self, llm, cache: NaiveCache, start_tokens, positions, max_length, use_graph=True, nsplit=None):
+    def __init__(self, llm, cache: NaiveCache, start_tokens, positions, max_length, use_graph=True, nsplit=None,
+                 fuse_norm=False):
         cfg, dev = llm.cfg, llm.device
         self.llm, self.cache, self.cfg, self.dev = llm, cache, cfg, dev
         B = len(cache.lens)
@@ -37,7 +38,8 @@ class DecodeSession:
         self.pred_ids = torch.zeros((max_length, B), dtype=torch.int64, device=dev)  # token predicted at each step
         self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)
         max_kv = max(cache.lens) + max_length + 1
-        self.nsplit = nsplit if nsplit is not None else (8 if max_kv >= 256 else 1)
+        # split the key range so that every wavefront walks ~2 blocks of 32 keys (latency bound otherwise)
+        self.nsplit = nsplit if nsplit is not None else max(1, min(32, (max_kv + 63) // 64))
         self.ws = ops.attn_workspace(B, nq, hd, 1, self.nsplit, dev) if self.nsplit > 1 else None
         self.max_kv = max_kv
         # static activations
@@ -49,6 +51,10 @@ class DecodeSession:
         self.act = torch.empty((B, cfg.inter), dtype=BF16, device=dev)
         self.hn = torch.empty((B, H), dtype=BF16, device=dev)
         self.logits = torch.empty((B, cfg.vocab), dtype=BF16, device=dev)
+        # RMSNorm can fold into the following GEMM's prologue (norm_w argument of umv_gemm_bf16), but on
+        # MI355X the per-workgroup normalise+stage prologue costs more than it saves at B=8
+        # (gate/up 47 -> 74 us, qkv 12 -> 22 us vs 57 x ~5 us of standalone norms), so it is off by default.
+        self.fuse_norm = fuse_norm and B <= 16 and H <= 4096
         self.steps_done = 0
         self.graph = None
         if use_graph:
@@ -61,18 +67,27 @@ class DecodeSession:
         ops.embed_gather(w.embed, self.ids, out=self.seq)
         for l in range(cfg.layers):
             lw = w.und[l]
-            ops.rmsnorm(self.seq, lw.in_norm, cfg.rms_eps, out=self.x)
-            ops.gemm(self.x, lw.qkv, out=self.qkv)
+            if self.fuse_norm:
+                ops.gemm(self.seq, lw.qkv, out=self.qkv, norm_w=lw.in_norm, norm_eps=cfg.rms_eps)
+            else:
+                ops.rmsnorm(self.seq, lw.in_norm, cfg.rms_eps, out=self.x)
+                ops.gemm(self.x, lw.qkv, out=self.qkv)
             ops.qkv_post(self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
                          cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin)
             ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
                           self.nsplit, self.ws)
             ops.gemm(self.o, lw.o, out=self.seq, residual=self.seq)
-            ops.rmsnorm(self.seq, lw.post_norm, cfg.rms_eps, out=self.x)
-            ops.gemm(self.x, lw.gate_up, out=self.act)
+            if self.fuse_norm:
+                ops.gemm(self.seq, lw.gate_up, out=self.act, norm_w=lw.post_norm, norm_eps=cfg.rms_eps)
+            else:
+                ops.rmsnorm(self.seq, lw.post_norm, cfg.rms_eps, out=self.x)
+                ops.gemm(self.x, lw.gate_up, out=self.act)
             ops.gemm(self.act, lw.down, out=self.seq, residual=self.seq)
-        ops.rmsnorm(self.seq, w.norm, cfg.rms_eps, out=self.hn)
-        ops.gemm(self.hn, w.lm_head, out=self.logits)
+        if self.fuse_norm:
+            ops.gemm(self.seq, w.lm_head, out=self.logits, norm_w=w.norm, norm_eps=cfg.rms_eps)
+        else:
+            ops.rmsnorm(self.seq, w.norm, cfg.rms_eps, out=self.hn)
+            ops.gemm(self.hn, w.lm_head, out=self.logits)
         ops.argmax(self.logits, out=self.ids)
         self.pred_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
         ops.decode_advance(self.tok_slot, self.tok_pos, self.kv_len)

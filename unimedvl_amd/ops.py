@@ -60,8 +60,10 @@ class PackedLinear:
         return self.wp.numel() * 2
 
 
-def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True):
-    """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}."""
+def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
+         norm_w=None, norm_eps=1e-6):
+    """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
+    norm_w: fuse Qwen2RMSNorm(x)*norm_w into the GEMM prologue (M <= 16, K <= 4096)."""
     lib = _lib.load()
     _req(x, BF16, "x")
     assert x.stride(-1) == 1
@@ -93,7 +95,8 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         ldr=residual.stride(0) if residual is not None else 0,
         out=out.data_ptr(), ldo=out.stride(0),
         row_idx=row_idx.data_ptr() if row_idx is not None else None,
-        M=M, N=lin.N, K=lin.K, epilogue=flags)
+        M=M, N=lin.N, K=lin.K, epilogue=flags,
+        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps)
     check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
     return out
 
