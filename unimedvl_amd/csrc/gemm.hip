@@ -16,6 +16,7 @@
 //     4 waves of 64x64, W fragments from the packed stream, x staged through LDS.
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
+#include <type_traits>
 
 // ----------------------------------------------------------------------------- packing
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ p, int N, int K, int NTT,
@@ -78,6 +79,15 @@ extern "C" int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t*
                        KT, I, up);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
 
 // ----------------------------------------------------------------------------- epilogue math
@@ -385,116 +395,157 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
 }
 
 // ----------------------------------------------------------------------------- tiled (M > 64)
-// Workgroup tile 128(n) x 128(m), 4 waves as 2(n) x 2(m), wave tile 64 x 64 = 4x4 MFMA tiles.
-// x tile (128 rows x 32 k) is staged through LDS in B-fragment order so each wave's four
-// x fragments are conflict-free 16-byte reads shared by the two waves of an m-half; W
-// fragments stream from the packed image (1 KiB contiguous per wave instruction).
-#define TG_BM 128
-#define TG_BN 128
-__global__ __launch_bounds__(256) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks) {
-    __shared__ __attribute__((aligned(16))) bf16_t xs[2][TG_BM / 16][64][8];  // [buf][m-tile][lane][8] = 2 x 8 KiB
+// Workgroup tile 128(n) x 128(m) x 64(k), 4 waves as 2(n) x 2(m), wave tile 64 x 64 = 4x4 MFMA
+// tiles, two LDS buffers of 32 KiB filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+// instruction) while the MFMAs of the previous k-step run:
+//   * the packed weight image IS the MFMA A-fragment order, so a W tile is a straight 1 KiB copy;
+//   * an x fragment (16 rows x 64 B) is gathered by giving every lane its own source address
+//     (row index list, K tail -> a zero page), so it lands in B-fragment order too.
+// Every ds_read_b128 is lane-linear (conflict free) and no fragment passes through VGPRs on its way in.
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_page[4] = {0, 0, 0, 0};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// WN x WM waves, each owning TN x TM MFMA tiles: workgroup tile (WN*TN*16)(n) x (WM*TM*16)(m) x 64(k).
+//   <2,2,4,4>: 128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU) - small / skewed problems
+//   <2,4,8,4>: 256 x 256, 8 waves, 128 KiB LDS (1 workgroup per CU) - halves the L2->LDS bytes per flop
+template <int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks) {
+    constexpr int NW = WN * WM;
+    constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+    constexpr int WTILES = BN / 16 * 2, XTILES = BM / 16 * 2;          // 1 KiB fragment tiles per k-step
+    constexpr int BUF = (WTILES + XTILES) * 1024;
+    static_assert(WTILES == NW / 2 * 8 && XTILES == NW / 2 * 8, "staging split: half the waves copy W, half gather x, 8 tiles each");
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][BUF]: W tiles [BN/16][2], then x tiles [BM/16][2]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int wn = wave & 1, wm = wave >> 1;
-    // m-blocks fastest so that co-running workgroups share one W panel in L2
-    const int mblk = blockIdx.x % mblocks;
-    const int nblk = blockIdx.x / mblocks;
-    const int m0 = mblk * TG_BM;
-    const int nt_base = nblk * (TG_BN / 16) + wn * 4;
+    const int wn = wave % WN, wm = wave / WN;
+    // XCD-aware order: blockIdx round-robins over the 8 XCDs, so give each XCD a contiguous run of
+    // tiles (m fastest) and let its private L2 keep one W panel hot.
+    const int nwg = mblocks * nblocks;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int mblk = bid % mblocks;
+    const int nblk = bid / mblocks;
+    const int m0 = mblk * BM;
+    const int nt_blk = nblk * (BN / 16);
+    const int nt_base = nt_blk + wn * TN;
+    const int nsteps = (KT + 1) / 2;
 
-    // staging role: thread -> (m-tile, lane) pairs; 8 m-tiles x 64 lanes = 512 fragments, 2 per thread
-    const bf16_t* srow[2];
-    bool svalid[2];
+    // ---- staging role: the first NW/2 waves copy W tiles, the others gather x tiles (8 tiles each)
+    const bf16_t* src[8];
+    const bool is_w = wave < NW / 2;
+    const int fbase = (wave % (NW / 2)) * 8;
+    bool tvalid[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = tid + i * 256;      // 0..511
-        int mt = f >> 6, l = f & 63;
-        int m = m0 + mt * 16 + (l & 15);
-        svalid[i] = m < a.M;
-        int64_t row = svalid[i] ? (a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m) : 0;
-        srow[i] = a.x + row * a.ldx + (l >> 4) * 8;
-    }
-    const bf16_t* wbase[4];
-    bool tvalid[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        tvalid[t] = (nt_base + t) < NTT;
-        wbase[t] = a.wp + ((int64_t)(tvalid[t] ? nt_base + t : 0) * KT) * 512 + lane * 8;
-    }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // prologue: stage k-tile 0
-    bf16x8 stage[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int k = (( (tid + i * 256) & 63) >> 4) * 8;
-        stage[i] = (svalid[i] && k < a.K) ? ldg_frag(srow[i]) : zero_frag();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = tid + i * 256;
-        *reinterpret_cast<bf16x8*>(&xs[0][f >> 6][f & 63][0]) = stage[i];
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        // issue next x tile loads (registers) and this tile's W fragment loads early
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int k = (kt + 1) * 32 + (((tid + i * 256) & 63) >> 4) * 8;
-                stage[i] = (svalid[i] && k < a.K) ? ldg_frag(srow[i] + (int64_t)(kt + 1) * 32) : zero_frag();
-            }
-        }
-        bf16x8 wf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wf[t] = ldg_frag(wbase[t] + (int64_t)kt * 512);
-        bf16x8 xf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(&xs[cur][wm * 4 + j][lane][0]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int f = tid + i * 256;
-                *reinterpret_cast<bf16x8*>(&xs[cur ^ 1][f >> 6][f & 63][0]) = stage[i];
-            }
-        }
-        __syncthreads();
-    }
-    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int m = m0 + (wm * 4 + j) * 16 + r;
-        if (m >= a.M) continue;
-        int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
-        if (a.epilogue & UMV_EPI_SWIGLU) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                int ntile = nt_base + 2 * p;
-                if (ntile >= NTT) continue;
-                int c0 = (ntile >> 1) * 16 + g * 4;
-                float gg[4] = {acc[2 * p][j].x, acc[2 * p][j].y, acc[2 * p][j].z, acc[2 * p][j].w};
-                float uu[4] = {acc[2 * p + 1][j].x, acc[2 * p + 1][j].y, acc[2 * p + 1][j].z, acc[2 * p + 1][j].w};
-                epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
-            }
+    for (int i = 0; i < 8; ++i) {
+        const int f = fbase + i;
+        const int tl = f >> 1, kk = f & 1;
+        if (is_w) {
+            const int nt = nt_blk + tl;
+            tvalid[i] = nt < NTT;
+            src[i] = a.wp + ((int64_t)(tvalid[i] ? nt : 0) * KT + kk) * 512 + lane * 8;
         } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int n0 = (nt_base + t) * 16 + g * 4;
-                if (n0 >= a.N) continue;
-                epi_store4(e, orow, n0, acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w);
-            }
+            const int m = m0 + tl * 16 + r;
+            tvalid[i] = true;                       // rows past M are clamped (their outputs are masked)
+            const int mm = m < a.M ? m : a.M - 1;
+            const int64_t row = a.row_idx ? (int64_t)a.row_idx[mm] : (int64_t)mm;
+            src[i] = a.x + row * a.ldx + kk * 32 + g * 8;
         }
     }
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto stage = [&](int step, int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = fbase + i;
+            const int kt = step * 2 + (f & 1);
+            const bf16_t* p;
+            if (is_w) {
+                p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)step * 1024 : zero;
+            } else {
+                const int k = kt * 32 + g * 8;
+                p = (k < a.K) ? src[i] + (int64_t)step * 64 : zero;
+            }
+            char* dst = smem + buf * BUF + (is_w ? 0 : WTILES * 1024) + f * 1024;
+            __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) before the barrier
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) stage(step + 1, cur ^ 1);
+        const char* wb = smem + cur * BUF;
+        const char* xb = wb + WTILES * 1024;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[TN], xf[TM];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + ((wn * TN + t) * 2 + kk) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + ((wm * TM + j) * 2 + kk) * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
+        }
+        __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    }
+    // epilogue with compile-time accumulator indices (a runtime-indexed acc[][] would be demoted to scratch)
+    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    const bool swiglu = (a.epilogue & UMV_EPI_SWIGLU) != 0;
+    static_for<0, TM>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const int m = m0 + (wm * TM + j) * 16 + r;
+        if (m < a.M) {
+            const int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+            if (swiglu) {
+                static_for<0, TN / 2>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    const int ntile = nt_base + 2 * p;
+                    if (ntile < NTT) {
+                        const int c0 = (ntile >> 1) * 16 + g * 4;
+                        float gg[4] = {acc[2 * p][j].x, acc[2 * p][j].y, acc[2 * p][j].z, acc[2 * p][j].w};
+                        float uu[4] = {acc[2 * p + 1][j].x, acc[2 * p + 1][j].y, acc[2 * p + 1][j].z, acc[2 * p + 1][j].w};
+                        epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
+                    }
+                });
+            } else {
+                static_for<0, TN>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const int n0 = (nt_base + t) * 16 + g * 4;
+                    if (n0 < a.N) epi_store4(e, orow, n0, acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w);
+                });
+            }
+        }
+    });
+}
+
+template <int WN, int WM, int TN, int TM>
+static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
+    constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+    constexpr size_t lds = 2 * (size_t)(BN / 16 * 2 + BM / 16 * 2) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT,
+                       mblocks, nblocks);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
 }
 
 template <int MB, int NT, int U, bool DB, bool NORM>
@@ -532,9 +583,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, false>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, false>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, false>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, false>(a, KT, NTT, s);
     }
-    int mblocks = (a.M + TG_BM - 1) / TG_BM;
-    int nblocks = (a.N + TG_BN - 1) / TG_BN;
-    hipLaunchKernelGGL(gemm_tiled_kernel, dim3(mblocks * nblocks), dim3(256), 0, s, a, KT, NTT, mblocks);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
+    const long big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    if (big >= 192) return launch_tiled<2, 4, 8, 4>(a, KT, NTT, s);
+    return launch_tiled<2, 2, 4, 4>(a, KT, NTT, s);
 }
