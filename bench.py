@@ -101,8 +101,78 @@ def cpu_baseline(batch, ctx, full_layers, seed=1234):
     }
 
 
+def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128, num_timesteps=50):
+    """BASELINE.json configs[2]: text-to-image, 50 diffusion steps, 256x256, batch 4 per GPU, the reference
+    defaults of InterleaveInferencer.gen_image (cfg_text 4.0, cfg_img 1.5, interval (0.4,1], shift 3.0, global
+    renorm): 49 Euler steps, 131 LLM gen-mode passes of 258 query tokens per image, then VAE decode to uint8."""
+    from copy import deepcopy
+    from unimedvl_amd.kvcache import NaiveCache
+    from unimedvl_amd.shapes import vae_shapes
+    from unimedvl_amd.vae import AutoEncoder
+    shapes = vae_shapes(cfg.to_dict())
+    vgen = torch.Generator(device=dev).manual_seed(4321)
+
+    def vget(name):
+        shp = shapes[name]
+        if len(shp) == 1:
+            return torch.ones(shp, device=dev, dtype=torch.bfloat16) if name.endswith("weight") else torch.zeros(shp, device=dev, dtype=torch.bfloat16)
+        fan_in = 1
+        for d in shp[1:]:
+            fan_in *= d
+        return (torch.randn(shp, device=dev, generator=vgen) / math.sqrt(fan_in)).to(torch.bfloat16)
+    vae = AutoEncoder(cfg, vget, device=dev)
+    ntid = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
+    g = torch.Generator().manual_seed(99 + rank)
+    hi = min(150000, cfg.vocab - 8)
+    prompts = [torch.randint(min(1000, hi // 2), hi, (prompt_len,), generator=g).tolist() for _ in range(batch)]
+    gen = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_prompts([0] * batch, [0] * batch, [str(i) for i in range(batch)], IdTokenizer(prompts), ntid)
+    gen = model.forward_cache_update_text(gen, **gi)
+    cfg_text = NaiveCache(cfg.layers)          # context without the prompt (inferencer.py:600)
+    cfg_img = deepcopy(gen)                    # context without images == the prompt only (inferencer.py:602)
+
+    def once(steps):
+        torch.manual_seed(7 + rank)
+        gl = model.prepare_vae_latent(kvl, rope, [(hw, hw)] * batch, ntid)
+        gt = model.prepare_vae_latent_cfg([0] * batch, [0] * batch, [(hw, hw)] * batch)
+        gim = model.prepare_vae_latent_cfg(kvl, rope, [(hw, hw)] * batch)
+        lat = model.generate_image(
+            past_key_values=gen, cfg_text_past_key_values=cfg_text, cfg_img_past_key_values=cfg_img,
+            num_timesteps=steps, cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0,
+            cfg_renorm_type="global", timestep_shift=3.0, **gl,
+            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"], cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=gt["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+            cfg_img_packed_position_ids=gim["cfg_packed_position_ids"], cfg_img_packed_query_indexes=gim["cfg_packed_query_indexes"],
+            cfg_img_key_values_lens=gim["cfg_key_values_lens"], cfg_img_packed_key_value_indexes=gim["cfg_packed_key_value_indexes"])
+        return [vae.decode_tokens_to_uint8(l, (hw, hw), model.latent_downsample, model.latent_patch_size) for l in lat]
+    once(3)                                    # warm-up (allocator, lazy module load)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    imgs = once(num_timesteps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert len(imgs) == batch and imgs[0].shape == (hw, hw, 3) and imgs[0].dtype == torch.uint8
+    ts = torch.linspace(1, 0, num_timesteps)
+    ts = (3.0 * ts / (1 + 2.0 * ts))[:-1]
+    passes = int(sum(3 if (t > 0.4 and t <= 1.0) else 1 for t in ts.tolist()))
+    return {"images_per_s": round(world * batch / el, 4), "unit": "images/s", "s_per_batch": round(el, 3), "batch_per_gpu": batch,
+            "image": f"{hw}x{hw}", "num_timesteps": num_timesteps, "llm_passes_per_image": passes, "prompt_tokens": prompt_len,
+            "cfg": "text 4.0, img 1.5, interval (0.4,1.0], renorm global, shift 3.0",
+            "workload": "configs[2]: UniMedVL-14B text-to-image, 50 diffusion steps, 256x256, batch=4, incl. VAE decode"}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--no-t2i", action="store_true", help="skip the text-to-image leg (configs[2])")
+    ap.add_argument("--t2i-steps", type=int, default=50)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
@@ -143,7 +213,8 @@ def main():
         img_hw, prompt_len = 56, 8
     B = args.batch
     t_load = time.time()
-    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=False, visual_und=True)
+    want_t2i = not args.no_t2i
+    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=want_t2i, visual_und=True)
     torch.cuda.synchronize()
     t_load = time.time() - t_load
 
@@ -249,6 +320,13 @@ def main():
                      "step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                      "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
     }
+    if want_t2i:
+        del sess, cache
+        torch.cuda.empty_cache()
+        if args.config == "full":
+            out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, num_timesteps=args.t2i_steps)
+        else:
+            out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, batch=2, hw=64, prompt_len=8, num_timesteps=6)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
         try:
             out["cpu_baseline"] = cpu_baseline(B, ctx, cfg.layers)

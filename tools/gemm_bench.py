@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Micro-benchmark of umv_gemm_bf16 on the model's GEMM shapes (TFLOP/s, random data).
+UMV_GEMM_TILE=<256|128|129|130|64> forces a tile configuration."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unimedvl_amd import ops
+
+def bench(M, N, K, swiglu=False, reps=20):
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    if swiglu:
+        lin = ops.PackedLinear.from_gate_up(torch.randn(N // 2, K, device="cuda").to(torch.bfloat16) * 0.02,
+                                            torch.randn(N // 2, K, device="cuda").to(torch.bfloat16) * 0.02)
+    else:
+        lin = ops.PackedLinear.from_weight(torch.randn(N, K, device="cuda").to(torch.bfloat16) * 0.02)
+    out = torch.empty(M, N // 2 if swiglu else N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm(x, lin, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm(x, lin, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    return us, 2.0 * M * N * K / us / 1e6
+
+shapes = [(1024, 4608, 3584, False), (1024, 3584, 3584, False), (1024, 37888, 3584, True), (1024, 3584, 18944, False),
+          (8208, 4608, 3584, False), (8208, 3584, 3584, False), (8208, 37888, 3584, True), (8208, 3584, 18944, False),
+          (8192, 3456, 1152, False), (8192, 1152, 1152, False), (8192, 4304, 1152, False), (8192, 1152, 4304, False),
+          (4096, 4096, 4096, False), (8192, 8192, 8192, False)]
+tag = os.environ.get("UMV_GEMM_TILE", "auto")
+for M, N, K, sw in shapes:
+    us, tf = bench(M, N, K, sw)
+    print(f"tile={tag:>4s} M={M:5d} N={N:6d} K={K:6d} {'swiglu' if sw else '      '} {us:9.1f} us {tf:8.1f} TF/s", flush=True)

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 #include <type_traits>
+#include <stdlib.h>
 
 // ----------------------------------------------------------------------------- packing
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ p, int N, int K, int NTT,
@@ -406,19 +407,24 @@ __device__ __attribute__((aligned(16))) const uint32_t g_zero_page[4] = {0, 0, 0
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// WN x WM waves, each owning TN x TM MFMA tiles: workgroup tile (WN*TN*16)(n) x (WM*TM*16)(m) x 64(k).
-//   <2,2,4,4>: 128 x 128, 4 waves, 64 KiB LDS (2 workgroups per CU) - small / skewed problems
-//   <2,4,8,4>: 256 x 256, 8 waves, 128 KiB LDS (1 workgroup per CU) - halves the L2->LDS bytes per flop
-template <int WN, int WM, int TN, int TM>
+// WN x WM waves, each owning TN x TM MFMA tiles: workgroup tile (WN*TN*16)(n) x (WM*TM*16)(m) x (KTS*32)(k),
+// NBUF LDS buffers.  Pipeline per k-step t (one raw s_barrier, never a full vmcnt drain in steady state):
+//     s_waitcnt vmcnt((NBUF-2) tiles)   my part of tile t has landed, tiles t+1.. stay in flight
+//     s_barrier                         everyone's part of tile t landed AND everyone finished reading tile t-1
+//     issue LDS-DMA for tile t+NBUF-1   into the buffer tile t-1 just vacated
+//     ds_read fragments of tile t, MFMAs
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
-    constexpr int WTILES = BN / 16 * 2, XTILES = BM / 16 * 2;          // 1 KiB fragment tiles per k-step
+    constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;      // 1 KiB fragment tiles per k-step
+    constexpr int TPW = (WTILES + XTILES) / NW;                          // tiles staged per wave per k-step
+    static_assert((WTILES + XTILES) % NW == 0, "staging tiles must divide evenly over the waves");
     constexpr int BUF = (WTILES + XTILES) * 1024;
-    static_assert(WTILES == NW / 2 * 8 && XTILES == NW / 2 * 8, "staging split: half the waves copy W, half gather x, 8 tiles each");
-    extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][BUF]: W tiles [BN/16][2], then x tiles [BM/16][2]
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // [NBUF][BUF]: W tiles [BN/16][KTS], then x tiles [BM/16][KTS]
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
     // XCD-aware order: blockIdx round-robins over the 8 XCDs, so give each XCD a contiguous run of
@@ -434,22 +440,22 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     const int m0 = mblk * BM;
     const int nt_blk = nblk * (BN / 16);
     const int nt_base = nt_blk + wn * TN;
-    const int nsteps = (KT + 1) / 2;
+    const int nsteps = (KT + KTS - 1) / KTS;
 
-    // ---- staging role: the first NW/2 waves copy W tiles, the others gather x tiles (8 tiles each)
-    const bf16_t* src[8];
-    const bool is_w = wave < NW / 2;
-    const int fbase = (wave % (NW / 2)) * 8;
-    bool tvalid[8];
+    // ---- staging: tile f = wave*TPW + i; f < WTILES copies a W tile, otherwise gathers an x tile
+    const bf16_t* src[TPW];
+    bool tvalid[TPW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = fbase + i;
-        const int tl = f >> 1, kk = f & 1;
-        if (is_w) {
+    for (int i = 0; i < TPW; ++i) {
+        const int f = wave * TPW + i;
+        if (f < WTILES) {
+            const int tl = f / KTS, kk = f % KTS;
             const int nt = nt_blk + tl;
             tvalid[i] = nt < NTT;
             src[i] = a.wp + ((int64_t)(tvalid[i] ? nt : 0) * KT + kk) * 512 + lane * 8;
         } else {
+            const int fx = f - WTILES;
+            const int tl = fx / KTS, kk = fx % KTS;
             const int m = m0 + tl * 16 + r;
             tvalid[i] = true;                       // rows past M are clamped (their outputs are masked)
             const int mm = m < a.M ? m : a.M - 1;
@@ -460,17 +466,18 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
     auto stage = [&](int step, int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = fbase + i;
-            const int kt = step * 2 + (f & 1);
+        for (int i = 0; i < TPW; ++i) {
+            const int f = wave * TPW + i;
             const bf16_t* p;
-            if (is_w) {
-                p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)step * 1024 : zero;
+            if (f < WTILES) {
+                const int kt = step * KTS + f % KTS;
+                p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)step * (KTS * 512) : zero;
             } else {
+                const int kt = step * KTS + (f - WTILES) % KTS;
                 const int k = kt * 32 + g * 8;
-                p = (k < a.K) ? src[i] + (int64_t)step * 64 : zero;
+                p = (k < a.K) ? src[i] + (int64_t)step * (KTS * 32) : zero;
             }
-            char* dst = smem + buf * BUF + (is_w ? 0 : WTILES * 1024) + f * 1024;
+            char* dst = smem + buf * BUF + f * 1024;
             __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_t)dst, 16, 0, 0);
         }
     };
@@ -480,26 +487,32 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) before the barrier
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p)
+        if (p < nsteps) stage(p, p);
     for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
-        if (step + 1 < nsteps) stage(step + 1, cur ^ 1);
+        const int cur = step % NBUF;
+        // tiles still allowed in flight behind tile `step`
+        const int ahead = min(NBUF - 2, nsteps - 1 - step);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
         const char* wb = smem + cur * BUF;
         const char* xb = wb + WTILES * 1024;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KTS; ++kk) {
             bf16x8 wf[TN], xf[TM];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + ((wn * TN + t) * 2 + kk) * 1024 + lane * 16);
+            for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + ((wn * TN + t) * KTS + kk) * 1024 + lane * 16);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + ((wm * TM + j) * 2 + kk) * 1024 + lane * 16);
+            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + ((wm * TM + j) * KTS + kk) * 1024 + lane * 16);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
         }
-        __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading `cur`
     }
     // epilogue with compile-time accumulator indices (a runtime-indexed acc[][] would be demoted to scratch)
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
@@ -531,19 +544,20 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     });
 }
 
-template <int WN, int WM, int TN, int TM>
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
 static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
-    constexpr size_t lds = 2 * (size_t)(BN / 16 * 2 + BM / 16 * 2) * 1024;
+    constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT,
-                       mblocks, nblocks);
+    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
+                       NTT, mblocks, nblocks);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -583,7 +597,24 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, false>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, false>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, false>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, false>(a, KT, NTT, s);
     }
-    const long big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if (big >= 192) return launch_tiled<2, 4, 8, 4>(a, KT, NTT, s);
-    return launch_tiled<2, 2, 4, 4>(a, KT, NTT, s);
+    // Tile choice from measurements on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 256x256x32
+    // 4-buffer tile wins whenever it yields about one workgroup per CU and K is long enough to amortise its
+    // prologue (950-980 TF/s on the prefill shapes); short-K (ViT, K=1152) and M~1024 problems that cannot
+    // fill 256 CUs with big tiles do better with 128(n)x64(m) (3 workgroups per CU) or 128x128 with two
+    // buffers (2 per CU).  UMV_GEMM_TILE=<256|128|129|130|64> overrides (tuning only).
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("UMV_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    const long wg256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    int cfg;
+    if (a.K < 2048) cfg = 64;
+    else if (wg256 >= 224) cfg = 256;
+    else if (wg128 >= 256) cfg = 129;
+    else cfg = 64;
+    if (force) cfg = force;
+    if (cfg == 256) return launch_tiled<2, 4, 8, 4, 1, 4>(a, KT, NTT, s);      // 256x256x32, 4 buffers (128 KiB)
+    if (cfg == 128) return launch_tiled<2, 2, 4, 4, 2, 3>(a, KT, NTT, s);      // 128x128x64, 3 buffers (96 KiB)
+    if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
+    if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
+    return launch_tiled<2, 2, 4, 2, 2, 3>(a, KT, NTT, s);                      // 128(n) x 64(m) x 64, 3 buffers (72 KiB)
 }
