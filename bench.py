@@ -301,6 +301,39 @@ def main():
     kv_tok = cfg.layers * 2 * cfg.kv_heads * cfg.head_dim * 2
     step_bytes = lw.decode_weight_bytes() + B * (ctx + args.warmup + args.steps / 2) * kv_tok + B * kv_tok + B * cfg.vocab * 2
 
+    # HBM traffic of the same kernel from PMC counters: collected by tools/pmc_traffic.sh (rocprofv3 --pmc, separate
+    # passes, gfx950 x2 correction of FETCH_SIZE) on this workload and committed under profiles/
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        if args.config == "full" and B == 8 and pm.get("algorithmic_bytes_per_launch") == int(bytes_per_launch):
+            traffic, traffic_src = int(pm["traffic_bytes_per_launch"]), "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate run)"
+    except Exception:
+        pass
+
+    # ---- ViT encode (MFMA-bound leg of the prefill): 8 x 448x448 through the SigLIP tower + connector
+    vit = None
+    if args.config == "full":
+        gi_v, _, _ = model.prepare_vit_images([0] * B, [0] * B, images, lambda x: x, new_token_ids)
+        px = gi_v["packed_vit_tokens"].to(dev)
+        pos_v = gi_v["packed_vit_position_ids"].to(dev)
+        model.encode_vit(px, pos_v, gi_v["vit_token_seqlens"])
+        torch.cuda.synchronize()
+        v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        v0.record()
+        for _ in range(3):
+            model.encode_vit(px, pos_v, gi_v["vit_token_seqlens"])
+        v1.record()
+        torch.cuda.synchronize()
+        vit_ms = v0.elapsed_time(v1) / 3
+        n_tok = px.shape[0]
+        vh, vi = cfg.vit_hidden, cfg.vit_inter
+        flops = 2 * n_tok * (cfg.vit_layers * (4 * vh * vh + 2 * vh * vi) + 3 * cfg.patch ** 2 * vh) \
+            + cfg.vit_layers * 4 * (n_tok // B) ** 2 * vh * B + 2 * n_tok * (vh * cfg.hidden + cfg.hidden * cfg.hidden)
+        vit = {"images_per_s": round(B / (vit_ms * 1e-3), 1), "ms_per_batch": round(vit_ms, 3), "batch": B,
+               "tflops": round(flops / (vit_ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (vit_ms * 1e-3) / 2.5e15, 4),
+               "note": "ViT tower + connector, 1024 patches/image; MFMA-bound (intensity ~700 flop/B), hd-72 attention included"}
+
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
     out = {
@@ -314,12 +347,14 @@ def main():
                    "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                    "prefill_s": round(t_prefill, 3), "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "gemm_skinny_kernel<1,2> (28 gate/up SwiGLU GEMMs + lm_head per step)",
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                      "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
     }
+    if vit is not None:
+        out["vit_encode"] = vit
     if want_t2i:
         del sess, cache
         torch.cuda.empty_cache()

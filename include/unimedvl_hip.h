@@ -153,6 +153,11 @@ int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);
  * slot[b]+=1, pos[b]+=1, kv_len[b]+=1 (the .tolist() bookkeeping of bagel.py:1266-1275,1303-1310) */
 int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int B, umv_stream_t stream);
 
+/* Stream `bytes` at `ptr` through the cache hierarchy (no compute) so that they are resident in the
+ * 256 MiB Infinity Cache for a later kernel; meant for a parallel stream / graph branch during the
+ * latency-bound kernels of a decode step.  `sink` (4 bytes, may be NULL) only keeps the loads alive. */
+int umv_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, umv_stream_t stream);
+
 /* ------------------------------------------------------------------ image head
  * CFG combine + renorm + Euler update (bagel.py:1173-1207, :983), bf16 rounding after each
  * op as the reference's bf16 tensors imply; x_t [N,D] fp32 updated in place.  v_* are

@@ -162,7 +162,7 @@ def test_t2i_latents(engine, rtype):
     ref = g["latent_" + rtype]
     d = (lat[0].cpu() - ref).abs()
     assert d.max().item() < 0.15 and d.mean().item() < 0.02, f"latent ({rtype}) max {d.max().item()} mean {d.mean().item()}"
-    assert gen.lens == cfg_img.lens and cfg_text.lens == [0], "flow passes must not commit KV"
+    assert gen.lens == cfg_img.lens and cfg_text.seq_lens == 0, "flow passes must not commit KV"
 
 
 def test_t2i_nocfg(engine):

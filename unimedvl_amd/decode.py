@@ -18,7 +18,7 @@ BF16 = torch.bfloat16
 
 class DecodeSession:
     def __init__(self, llm, cache: NaiveCache, start_tokens, positions, max_length, use_graph=True, nsplit=None,
-                 fuse_norm=False):
+                 fuse_norm=False, prefetch=None):
         cfg, dev = llm.cfg, llm.device
         self.llm, self.cache, self.cfg, self.dev = llm, cache, cfg, dev
         B = len(cache.lens)
@@ -55,32 +55,70 @@ class DecodeSession:
         # MI355X the per-workgroup normalise+stage prologue costs more than it saves at B=8
         # (gate/up 47 -> 74 us, qkv 12 -> 22 us vs 57 x ~5 us of standalone norms), so it is off by default.
         self.fuse_norm = fuse_norm and B <= 16 and H <= 4096
+        # Experimental (OFF): weight prefetch into the Infinity Cache on a parallel graph branch during the
+        # latency-bound kernels (window sizes in MiB).  Measured on MI355X: the branch does not overlap with the
+        # main chain under hipGraph replay and the step gets SLOWER (3.43 -> 4.5-5.4 ms), so it stays disabled;
+        # UMV_DECODE_PREFETCH=1 re-enables it for experiments.
+        import os
+        pf = os.environ.get("UMV_DECODE_PREFETCH", "0" if prefetch is None else str(int(prefetch)))
+        self.prefetch = pf not in ("0", "") and use_graph
+        self.pf_w1 = int(os.environ.get("UMV_PF_W1", "24"))
+        self.pf_w2 = int(os.environ.get("UMV_PF_W2", "64"))
+        self.pf_w3 = int(os.environ.get("UMV_PF_W3", "24"))
+        self.pf_blocks = int(os.environ.get("UMV_PF_BLOCKS", "128"))
+        self.pf_stream = torch.cuda.Stream(device=dev) if self.prefetch else None
         self.steps_done = 0
         self.graph = None
         if use_graph:
             self._capture()
 
+    def _prefetch(self, jobs):
+        """Fork: stream the given (tensor, offset, nbytes) weight ranges into the Infinity Cache on the side
+        stream while the main stream runs latency-bound kernels.  Returns nothing; call _join() before the
+        consumer so the branch rejoins the (captured) main stream."""
+        if not self.prefetch:
+            return
+        main = torch.cuda.current_stream()
+        self.pf_stream.wait_stream(main)
+        for t, off, n in jobs:
+            ops.prefetch(t, n, off, blocks=self.pf_blocks, stream=self.pf_stream)
+
+    def _join(self):
+        if self.prefetch:
+            torch.cuda.current_stream().wait_stream(self.pf_stream)
+
     def _step(self):
         cfg, w, c = self.cfg, self.llm.w, self.cache
         nq, nkv, hd = cfg.heads, cfg.kv_heads, cfg.head_dim
+        MB = 1 << 20
         self.in_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
         ops.embed_gather(w.embed, self.ids, out=self.seq)
         for l in range(cfg.layers):
             lw = w.und[l]
+            # window 1 (input norm): start pulling the QKV weights
+            self._prefetch([(lw.qkv.wp, 0, self.pf_w1 * MB)])
             if self.fuse_norm:
+                self._join()
                 ops.gemm(self.seq, lw.qkv, out=self.qkv, norm_w=lw.in_norm, norm_eps=cfg.rms_eps)
             else:
                 ops.rmsnorm(self.seq, lw.in_norm, cfg.rms_eps, out=self.x)
+                self._join()
                 ops.gemm(self.x, lw.qkv, out=self.qkv)
+            # window 2 (RoPE/KV append, attention, combine): o_proj weights and the head of gate/up
+            self._prefetch([(lw.o.wp, 0, None), (lw.gate_up.wp, 0, self.pf_w2 * MB)])
             ops.qkv_post(self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
                          cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin)
             ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
                           self.nsplit, self.ws)
+            self._join()
             ops.gemm(self.o, lw.o, out=self.seq, residual=self.seq)
             if self.fuse_norm:
                 ops.gemm(self.seq, lw.gate_up, out=self.act, norm_w=lw.post_norm, norm_eps=cfg.rms_eps)
             else:
+                # window 3 (post-attention norm): a little more of gate/up
+                self._prefetch([(lw.gate_up.wp, self.pf_w2 * MB, self.pf_w3 * MB)])
                 ops.rmsnorm(self.seq, lw.post_norm, cfg.rms_eps, out=self.x)
+                self._join()
                 ops.gemm(self.x, lw.gate_up, out=self.act)
             ops.gemm(self.act, lw.down, out=self.seq, residual=self.seq)
         if self.fuse_norm:

@@ -85,6 +85,36 @@ class NaiveCache:
         """Pre-size (bench / serving) so that decode never re-allocates."""
         self.ensure(nseg, cap, nkv, hd, device)
 
+    @staticmethod
+    def merged(caches, nsegs, extra, nkv, hd, device):
+        """One cache whose segments are the segments of `caches` back to back (contexts that hold
+        different tokens for the same samples, e.g. the three CFG contexts of bagel.py:1120-1171),
+        with room for `extra` more tokens per segment.  Lets independent passes run as ONE packed
+        forward.  `nsegs[i]` = samples in caches[i] (needed for caches that are still empty)."""
+        lens = []
+        for c, n in zip(caches, nsegs):
+            lens += list(c.lens) if c.slabs is not None else [0] * n
+        m = NaiveCache(caches[0].num_layers)
+        m.ensure(len(lens), max(lens) + extra, nkv, hd, device)
+        m.lens = lens
+        base = 0
+        for c, n in zip(caches, nsegs):
+            if c.slabs is not None and max(c.lens) > 0:
+                keep = _round_up(max(c.lens), 32)
+                for dst, src in zip(m.slabs, c.slabs):
+                    dst.k[base:base + n, :, :keep].copy_(src.k[:, :, :keep])
+                    dst.vt[base:base + n, :, :, :keep].copy_(src.vt[:, :, :, :keep])
+            base += n
+        return m
+
+    def view_segments(self, start, end):
+        """A cache over segments [start, end) sharing this cache's memory (no copy)."""
+        v = NaiveCache(self._num_layers)
+        v.lens = list(self.lens[start:end])
+        v.nkv, v.hd, v.device = self.nkv, self.hd, self.device
+        v.slabs = [ops.KVSlab.from_tensors(s.k[start:end], s.vt[start:end]) for s in self.slabs]
+        return v
+
     def __deepcopy__(self, memo):
         c = NaiveCache(self._num_layers)
         c.lens = list(self.lens)

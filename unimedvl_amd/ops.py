@@ -168,6 +168,15 @@ class KVSlab:
         self.vt = torch.zeros((nseg, nkv, hd, cap), dtype=BF16, device=device)
         self.nseg, self.nkv, self.cap, self.hd = nseg, nkv, cap, hd
 
+    @staticmethod
+    def from_tensors(k, vt):
+        """Wrap existing (possibly sliced along the segment dim) slab tensors."""
+        s = KVSlab.__new__(KVSlab)
+        s.k, s.vt = k, vt
+        s.nseg, s.nkv, s.cap, s.hd = k.shape
+        assert k.stride(3) == 1 and k.stride(2) == s.hd and k.stride(1) == s.cap * s.hd and k.stride(0) == s.nkv * s.cap * s.hd
+        return s
+
     def strides(self):
         return dict(k_seg_stride=self.nkv * self.cap * self.hd, k_head_stride=self.cap * self.hd,
                     v_seg_stride=self.nkv * self.hd * self.cap, v_head_stride=self.hd * self.cap, v_d_stride=self.cap)
@@ -220,3 +229,14 @@ def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img
     check(lib.umv_cfg_renorm_euler(_p(x_t), _p(v_t), _p(v_text), _p(v_img), v_t.stride(0), _p(rows), _p(seg_off), nseg,
                                    float(s_text), float(s_img), float(renorm_min), int(rtype), float(dt), x_t.shape[1],
                                    _stream()), "umv_cfg_renorm_euler")
+
+
+def prefetch(t, nbytes=None, offset=0, blocks=128, stream=None):
+    """Pull `nbytes` of tensor `t` (from byte `offset`) into L2 / Infinity Cache on `stream` (default: current)."""
+    lib = _lib.load()
+    total = t.numel() * t.element_size()
+    nbytes = total - offset if nbytes is None else min(nbytes, total - offset)
+    if nbytes <= 0:
+        return
+    st = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
+    check(lib.umv_prefetch(C.c_void_p(t.data_ptr() + offset), nbytes, blocks, None, st), "umv_prefetch")
