@@ -34,6 +34,11 @@ const char* umv_last_error(void);
  * so that a wavefront streams 1 KiB contiguous per 16x32 tile. */
 size_t umv_packed_weight_elems(int N, int K);
 int umv_pack_weight_bf16(const uint16_t* w, uint16_t* packed, int N, int K, umv_stream_t stream);
+/* Decode-only second copy with `th`-row tiles, Q[n/th][k/32][(k%32)/8][n%th][k%8], built from the standard
+ * image: with th = N/256 (14 for N=3584, 9 for N=4608) the weight-streaming GEMM has exactly one (or two)
+ * tiles per CU of the 256-CU chip instead of 224-288 16-row tiles. */
+size_t umv_repacked_weight_elems(int N, int K, int th);
+int umv_repack_weight_rows_bf16(const uint16_t* packed16, uint16_t* out, int N, int K, int th, umv_stream_t stream);
 /* gate_proj / up_proj [I,K] each -> one packed [2I,K] with 16-row tiles interleaved
  * (gate tile t, up tile t, ...) so SwiGLU fuses into the GEMM epilogue. */
 int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int I, int K,
@@ -72,6 +77,8 @@ typedef struct {
                                  qwen2_navit.py:861,888,1164 feeding :541-543, modeling_qwen2.py:234, bagel.py:1295);
                                  needs M <= 16 and K <= 4096 */
     float norm_eps;
+    int tile_rows;            /* rows per n-tile of `wp`: 0 or 16 = umv_pack_weight_bf16 image; 1..15 = an image made by
+                                 umv_repack_weight_rows_bf16 (decode only, M <= 64) */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 
@@ -94,6 +101,11 @@ int umv_add_rows_bf16(const uint16_t* a, const uint16_t* bcast, const uint16_t* 
                       const int32_t* out_rows, uint16_t* out, int T, int H, umv_stream_t stream);
 /* greedy sampling (bagel.py:1301): argmax over bf16 logits, lowest index wins ties */
 int umv_argmax_bf16(const uint16_t* logits, int64_t ld, int64_t* out_ids, int M, int V, umv_stream_t stream);
+/* do_sample=True (bagel.py:1297-1299): token = multinomial(softmax(logits / temperature), 1), drawn as
+ * argmax(p_i / q_i), q_i ~ Exp(1), from a counter-based generator keyed by (seed, *step, row, i); `step`
+ * is an optional device counter so the call replays from a hipGraph.  Reproducible per seed; not torch's stream. */
+int umv_sample_bf16(const uint16_t* logits, int64_t ld, int64_t* out_ids, int M, int V, float temperature, uint64_t seed,
+                    const int64_t* step, umv_stream_t stream);
 /* pixels [N, 3*p*p] fp32 -> bf16 [N, Kp] zero padded (cast that autocast applies before
  * the patch-embed linear, siglip_navit.py:190) */
 int umv_cast_pad_f32_bf16(const float* x, int64_t ldx, uint16_t* out, int64_t ldo, int T, int K, int Kp,

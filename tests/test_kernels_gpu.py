@@ -119,6 +119,20 @@ def test_gemm_fused_rmsnorm(ops, M, N, K, swiglu):
     assert_close_bf16(out, two_step.cpu(), what="fused vs two-step", frac_exact=0.97)
 
 
+@pytest.mark.parametrize("M,N,K", [(8, 3584, 3584), (8, 4608, 3584), (8, 3584, 18944), (20, 2560, 256), (3, 3584, 64)])
+def test_gemm_exact_partition_tiles(ops, M, N, K):
+    """decode-only th-row weight image (th = N/256): same result as the standard 16-row image."""
+    x, w, b, res = rnd((M, K), 70), rnd((N, K), 71, 1 / math.sqrt(K)), rnd((N,), 72), rnd((M, N), 73)
+    lin = ops.PackedLinear.from_weight(w.cuda(), b.cuda())
+    dec = lin.for_decode()
+    assert dec.th < 16 and N % dec.th == 0 and (N // dec.th) % 256 == 0
+    ref = ops.gemm(x.cuda(), lin, residual=res.cuda())
+    out = ops.gemm(x.cuda(), dec, residual=res.cuda())
+    assert torch.equal(out.cpu(), ref.cpu()), "exact-partition tiles must not change a single bit"
+    with pytest.raises(Exception):
+        ops.gemm(rnd((100, K), 74).cuda(), dec)      # decode-only layout
+
+
 def test_norms(ops):
     from oracle.unimedvl_cpu import rmsnorm
     for T, H in [(8, 3584), (5, 256), (300, 128), (1000, 1152)]:
@@ -163,6 +177,39 @@ def test_gather_add_argmax(ops):
     px = torch.randn(10, 588, generator=torch.Generator().manual_seed(35))
     cp = ops.cast_pad(px.cuda(), 608).cpu()
     assert torch.equal(cp[:, :588], px.to(BF16)) and (cp[:, 588:] == 0).all()
+
+
+def test_sampling_matches_softmax_distribution(ops):
+    """do_sample path (bagel.py:1297-1299): empirical frequencies of umv_sample_bf16 follow
+    softmax(logits / T); same seed -> same draw; different steps -> different draws."""
+    V, T = 40, 0.7
+    g = torch.Generator().manual_seed(80)
+    logits = (torch.randn(1, V, generator=g) * 2).to(BF16)
+    p = torch.softmax((logits.float() / T).to(BF16).float(), -1)[0]
+    rows = 4096
+    big = logits.repeat(rows, 1).cuda()
+    counts = torch.zeros(V)
+    for s in range(4):
+        ids = ops.sample(big, T, seed=1234 + s).cpu()
+        assert int(ids.min()) >= 0 and int(ids.max()) < V
+        counts += torch.bincount(ids, minlength=V).float()
+    n = counts.sum()
+    exp = p * n
+    mask = exp > 5
+    chi2 = (((counts - exp) ** 2) / exp)[mask].sum().item()
+    dof = int(mask.sum()) - 1
+    assert chi2 < dof + 6 * (2 * dof) ** 0.5, f"chi2 {chi2:.1f} for {dof} dof"
+    a = ops.sample(big, T, seed=99).cpu()
+    b = ops.sample(big, T, seed=99).cpu()
+    assert torch.equal(a, b)
+    step = torch.tensor([7], dtype=torch.int64, device="cuda")
+    c = ops.sample(big, T, seed=99, step=step).cpu()
+    assert not torch.equal(a, c)
+    # temperature -> 0 approaches greedy
+    cold = ops.sample(big[:64], 0.01, seed=5).cpu()
+    assert (cold == int(logits.float().argmax())).all()
+    with pytest.raises(Exception):
+        ops.sample(big, 0.0, seed=1)
 
 
 def _rope_tables(max_pos, hd, theta=1e6):

@@ -19,7 +19,7 @@ class GemmArgs(C.Structure):
         ("x", C.c_void_p), ("ldx", C.c_int64), ("wp", C.c_void_p), ("bias", C.c_void_p),
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
         ("row_idx", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
-        ("norm_w", C.c_void_p), ("norm_eps", C.c_float),
+        ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("tile_rows", C.c_int),
     ]
 
 
@@ -62,6 +62,8 @@ _SIGS = {
     "umv_last_error": (C.c_char_p, []),
     "umv_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "umv_pack_weight_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "umv_repacked_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "umv_repack_weight_rows_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "umv_pack_weight_swiglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "umv_rmsnorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -72,6 +74,8 @@ _SIGS = {
     "umv_add_rows_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_void_p]),
     "umv_argmax_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "umv_sample_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p,
+                                  C.c_void_p]),
     "umv_cast_pad_f32_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
     "umv_qkv_post": (C.c_int, [C.POINTER(QkvPostArgs), C.c_void_p]),

@@ -254,12 +254,15 @@ class Bagel(BagelPrep):
         start tokens.  Like the reference, the batch stops when SAMPLE 0 emits end_token_id
         (bagel.py:1313); per_sample_eos=True is the batched extension (stops when every sample
         has emitted it; rows after a sample's EOS keep decoding and should be ignored)."""
-        if do_sample:
-            raise NotImplementedError("sampling (multinomial) is a 'next' row; greedy only")
+        # do_sample: softmax(logits / temperature) + multinomial on the device (bagel.py:1297-1299).  The
+        # draw is keyed by a seed taken from torch's CPU generator, so torch.manual_seed(s) makes runs
+        # reproducible; the stream itself is not torch's (no device can reproduce another's RNG).
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0
         if key_values_lens is not None and [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
             raise ValueError("key_values_lens disagree with the cache")
         sess = DecodeSession(self.language_model, past_key_values, packed_start_tokens, packed_query_position_ids,
-                             max_length, use_graph=self.decode_use_graph and not return_logits)
+                             max_length, use_graph=self.decode_use_graph and not return_logits,
+                             do_sample=do_sample, temperature=temperature, seed=seed)
         logits = []
         steps = 0
         stop = None

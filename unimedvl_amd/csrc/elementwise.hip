@@ -295,6 +295,88 @@ extern "C" int umv_argmax_bf16(const uint16_t* logits, int64_t ld, int64_t* out_
     return UMV_OK;
 }
 
+// ----------------------------------------------------------------------------- temperature sampling
+// bagel.py:1297-1299: probs = softmax(logits / temperature) ; token = multinomial(probs, 1).
+// torch draws one sample without replacement as argmax(probs / q), q ~ Exp(1) per element; this kernel
+// does the same with a counter-based generator (splitmix64 of (seed, step, row, index)), so the stream is
+// reproducible for a given seed but is NOT torch's CPU/CUDA stream.  Rounding follows the bf16 tensors of
+// the reference: logits/T -> bf16, softmax output -> bf16.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ float block_reduce_max(float v, float* sm) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sm[w]);
+    return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sm[w];
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void sample_kernel(const bf16_t* __restrict__ logits, int64_t ld, int64_t* __restrict__ out, int V,
+                                                      float temp, uint64_t seed, const int64_t* __restrict__ step_ptr) {
+    __shared__ float smf[16];
+    __shared__ int smi[16];
+    const int m = blockIdx.x;
+    const bf16_t* row = logits + (int64_t)m * ld;
+    const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : 0ull;
+    const uint64_t key = splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull) ^ ((uint64_t)m << 32));
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, rbf(bf2f(row[i]) / temp));
+    mx = block_reduce_max(mx, smf);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) sum += expf(rbf(bf2f(row[i]) / temp) - mx);
+    sum = block_reduce_sum(sum, smf);
+    float best = -1.f;
+    int bidx = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float p = rbf(expf(rbf(bf2f(row[i]) / temp) - mx) / sum);
+        const uint64_t h = splitmix64(key + (uint64_t)i);
+        const float u = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+        const float q = -logf(u);                                           // Exp(1); q > 0 except u == 1
+        const float sc = q > 0.f ? p / q : (p > 0.f ? INFINITY : 0.f);
+        if (sc > best || (sc == best && i < bidx)) { best = sc; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { smf[threadIdx.x >> 6] = best; smi[threadIdx.x >> 6] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (smf[w] > best || (smf[w] == best && smi[w] < bidx)) { best = smf[w]; bidx = smi[w]; }
+        out[m] = bidx;
+    }
+}
+
+extern "C" int umv_sample_bf16(const uint16_t* logits, int64_t ld, int64_t* out_ids, int M, int V, float temperature, uint64_t seed,
+                               const int64_t* step, umv_stream_t stream) {
+    UMV_CHECK(logits && out_ids && V > 0, UMV_ERR_ARG, "sample: bad args");
+    UMV_CHECK(temperature > 0.f, UMV_ERR_ARG, "sample: temperature must be > 0 (got %g)", (double)temperature);
+    if (M == 0) return UMV_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, logits, ld, out_ids, V, temperature, seed, step);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
 // ----------------------------------------------------------------------------- fp32 -> bf16 with zero padding
 __global__ void cast_pad_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int T, int K, int Kp) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,6 +54,37 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restr
     *reinterpret_cast<u32x4*>(p + gid * 8) = o;
 }
 
+// Re-tile a standard packed image (16-row tiles) into `th`-row tiles for the decode GEMM:
+//   Q[n/th][k/32][g][r < th][k%8]   (th <= 16; th == 16 is the standard image)
+// With th = N / 256 (e.g. 14 rows for N = 3584) the skinny GEMM gets exactly one tile per CU.
+__global__ void repack_rows_kernel(const bf16_t* __restrict__ p16, bf16_t* __restrict__ q, int N, int KT, int th, int64_t total) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element group per thread
+    if (gid >= total) return;
+    const int r = (int)(gid % th);
+    const int g = (int)((gid / th) % 4);
+    const int kt = (int)((gid / (4 * th)) % KT);
+    const int64_t nt = gid / ((int64_t)4 * th * KT);
+    const int64_t n = nt * th + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N) v = *reinterpret_cast<const u32x4*>(p16 + (((n >> 4) * KT + kt) * 64 + g * 16 + (n & 15)) * 8);
+    *reinterpret_cast<u32x4*>(q + gid * 8) = v;
+}
+
+extern "C" size_t umv_repacked_weight_elems(int N, int K, int th) {
+    size_t nt = ((size_t)N + th - 1) / th, kt = (size_t)(K + 31) / 32;
+    return nt * kt * 4 * th * 8;
+}
+
+extern "C" int umv_repack_weight_rows_bf16(const uint16_t* packed16, uint16_t* out, int N, int K, int th, umv_stream_t stream) {
+    UMV_CHECK(packed16 && out && N > 0 && K > 0 && th >= 1 && th <= 16, UMV_ERR_ARG, "repack_weight_rows: bad args (th=%d)", th);
+    const int KT = (K + 31) / 32;
+    const int64_t total = (int64_t)((N + th - 1) / th) * KT * 4 * th;
+    hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed16, out, N,
+                       KT, th, total);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
 extern "C" size_t umv_packed_weight_elems(int N, int K) {
     size_t ntt = (size_t)(N + 15) / 16, kt = (size_t)(K + 31) / 32;
     return ntt * kt * 512;
@@ -222,11 +253,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
     const int kt_end = min(KT, kt_begin + kt_per);
     const int nk = max(0, kt_end - kt_begin);
     const int nchunks = (nk + U - 1) / U;
+    // TH = rows per n-tile of the packed image (16 standard; < 16 for the exact-partition decode copies,
+    // whose lanes r >= TH carry no row): tile (nt, kt) holds [g][r < TH][8] = 4*TH*8 elements
+    const int TH = a.tile_rows > 0 ? a.tile_rows : 16;
+    const int tile_elems = 4 * TH * 8;
+    const bool rowlane = r < TH;
     const bf16_t* wbase[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const bool tv = (nt0 + t) < NTT;
-        wbase[t] = a.wp + ((int64_t)(tv ? nt0 + t : 0) * KT) * 512 + lane * 8;
+        wbase[t] = a.wp + ((int64_t)(tv ? nt0 + t : 0) * KT) * tile_elems + (g * TH + (rowlane ? r : 0)) * 8;
     }
     auto load_chunk = [&](int c, SkBuf<MB, NT, U>& b) {
 #pragma unroll
@@ -235,7 +271,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
             const bool ok = kt < kt_end;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                b.w[u][t] = ok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wbase[t] + (int64_t)kt * 512)) : zero_frag();
+                b.w[u][t] = (ok && rowlane) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wbase[t] + (int64_t)kt * tile_elems))
+                                            : zero_frag();
             if (!NORM) {
                 const int k = kt * 32 + g * 8;
 #pragma unroll
@@ -386,10 +423,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
 #pragma unroll
             for (int w = 0; w < SK_WAVES; ++w) s += reinterpret_cast<f32x4*>(red)[(w * E4 + f) * 64 + l];
             int m = mb * 16 + (l & 15);
-            int n0 = (nt0 + t) * 16 + (l >> 4) * 4;
-            if (m < a.M && n0 < a.N) {
+            int n0 = (nt0 + t) * TH + (l >> 4) * 4;
+            int nend = min(a.N, (nt0 + t) * TH + TH);            // rows of this tile stop at TH
+            if (m < a.M && n0 < nend) {
                 int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
-                epi_store4(e, orow, n0, s.x, s.y, s.z, s.w);
+                EpiCtx et = e;
+                et.N = nend;
+                epi_store4(et, orow, n0, s.x, s.y, s.z, s.w);
             }
         }
     }
@@ -587,7 +627,11 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 31) / 32;
-    const int NTT = (a.N + 15) / 16;
+    const int TH = a.tile_rows > 0 ? a.tile_rows : 16;
+    UMV_CHECK(TH <= 16, UMV_ERR_ARG, "gemm: tile_rows %d > 16", TH);
+    UMV_CHECK(TH == 16 || (a.M <= 64 && !(a.epilogue & UMV_EPI_SWIGLU)), UMV_ERR_UNSUPPORTED,
+              "gemm: %d-row packed tiles are a decode-only layout (M <= 64, no SwiGLU)", TH);
+    const int NTT = (a.N + TH - 1) / TH;
     if (a.M <= 64) {
         const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
         if (a.M <= 16) {
@@ -607,8 +651,10 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     const long wg256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     int cfg;
+    const long wg258 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
     if (a.K < 2048) cfg = 64;
-    else if (wg256 >= 224) cfg = 256;
+    else if (wg256 >= 160) cfg = 256;      // e.g. guided flow M=3072: 168 tiles still beat smaller tiles (660-775 vs 500-610 TF/s)
+    else if (wg258 >= 200) cfg = 258;      // M~2048: 256(n) x 128(m), 8 waves
     else if (wg128 >= 256) cfg = 129;
     else cfg = 64;
     if (force) cfg = force;
@@ -616,5 +662,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 128) return launch_tiled<2, 2, 4, 4, 2, 3>(a, KT, NTT, s);      // 128x128x64, 3 buffers (96 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
+    if (cfg == 257) return launch_tiled<2, 4, 8, 2, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves, 4 buffers (96 KiB)
+    if (cfg == 258) return launch_tiled<4, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves as 4x2 (96 KiB)
+    if (cfg == 259) return launch_tiled<2, 4, 4, 4, 1, 4>(a, KT, NTT, s);      // 128(n)x256(m)x32, 8 waves (96 KiB)
     return launch_tiled<2, 2, 4, 2, 2, 3>(a, KT, NTT, s);                      // 128(n) x 64(m) x 64, 3 buffers (72 KiB)
 }

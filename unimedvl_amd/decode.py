@@ -18,7 +18,7 @@ BF16 = torch.bfloat16
 
 class DecodeSession:
     def __init__(self, llm, cache: NaiveCache, start_tokens, positions, max_length, use_graph=True, nsplit=None,
-                 fuse_norm=False, prefetch=None):
+                 fuse_norm=False, prefetch=None, do_sample=False, temperature=1.0, seed=0):
         cfg, dev = llm.cfg, llm.device
         self.llm, self.cache, self.cfg, self.dev = llm, cache, cfg, dev
         B = len(cache.lens)
@@ -67,6 +67,13 @@ class DecodeSession:
         self.pf_w3 = int(os.environ.get("UMV_PF_W3", "24"))
         self.pf_blocks = int(os.environ.get("UMV_PF_BLOCKS", "128"))
         self.pf_stream = torch.cuda.Stream(device=dev) if self.prefetch else None
+        # decode-only weight copies with exact-partition tiles (N/256 rows per tile) for the N=3584-class GEMMs
+        exact = os.environ.get("UMV_DECODE_EXACT_TILES", "1") not in ("0", "") and B <= 64
+        w = llm.w
+        if exact and not hasattr(w, "decode_copies"):
+            w.decode_copies = [(lw.qkv.for_decode(), lw.o.for_decode(), lw.down.for_decode()) for lw in w.und]
+        self.dec = w.decode_copies if exact else [(lw.qkv, lw.o, lw.down) for lw in w.und]
+        self.do_sample, self.temperature, self.seed = bool(do_sample), float(temperature), int(seed)
         self.steps_done = 0
         self.graph = None
         if use_graph:
@@ -96,22 +103,23 @@ class DecodeSession:
         for l in range(cfg.layers):
             lw = w.und[l]
             # window 1 (input norm): start pulling the QKV weights
-            self._prefetch([(lw.qkv.wp, 0, self.pf_w1 * MB)])
+            qkv_w, o_w, down_w = self.dec[l]
+            self._prefetch([(qkv_w.wp, 0, self.pf_w1 * MB)])
             if self.fuse_norm:
                 self._join()
-                ops.gemm(self.seq, lw.qkv, out=self.qkv, norm_w=lw.in_norm, norm_eps=cfg.rms_eps)
+                ops.gemm(self.seq, qkv_w, out=self.qkv, norm_w=lw.in_norm, norm_eps=cfg.rms_eps)
             else:
                 ops.rmsnorm(self.seq, lw.in_norm, cfg.rms_eps, out=self.x)
                 self._join()
-                ops.gemm(self.x, lw.qkv, out=self.qkv)
+                ops.gemm(self.x, qkv_w, out=self.qkv)
             # window 2 (RoPE/KV append, attention, combine): o_proj weights and the head of gate/up
-            self._prefetch([(lw.o.wp, 0, None), (lw.gate_up.wp, 0, self.pf_w2 * MB)])
+            self._prefetch([(o_w.wp, 0, None), (lw.gate_up.wp, 0, self.pf_w2 * MB)])
             ops.qkv_post(self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
                          cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin)
             ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
                           self.nsplit, self.ws)
             self._join()
-            ops.gemm(self.o, lw.o, out=self.seq, residual=self.seq)
+            ops.gemm(self.o, o_w, out=self.seq, residual=self.seq)
             if self.fuse_norm:
                 ops.gemm(self.seq, lw.gate_up, out=self.act, norm_w=lw.post_norm, norm_eps=cfg.rms_eps)
             else:
@@ -120,13 +128,16 @@ class DecodeSession:
                 ops.rmsnorm(self.seq, lw.post_norm, cfg.rms_eps, out=self.x)
                 self._join()
                 ops.gemm(self.x, lw.gate_up, out=self.act)
-            ops.gemm(self.act, lw.down, out=self.seq, residual=self.seq)
+            ops.gemm(self.act, down_w, out=self.seq, residual=self.seq)
         if self.fuse_norm:
             ops.gemm(self.seq, w.lm_head, out=self.logits, norm_w=w.norm, norm_eps=cfg.rms_eps)
         else:
             ops.rmsnorm(self.seq, w.norm, cfg.rms_eps, out=self.hn)
             ops.gemm(self.hn, w.lm_head, out=self.logits)
-        ops.argmax(self.logits, out=self.ids)
+        if self.do_sample:
+            ops.sample(self.logits, self.temperature, self.seed, step=self.step_idx, out=self.ids)
+        else:
+            ops.argmax(self.logits, out=self.ids)
         self.pred_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
         ops.decode_advance(self.tok_slot, self.tok_pos, self.kv_len)
         self.step_idx.add_(1)

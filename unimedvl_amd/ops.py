@@ -31,10 +31,27 @@ def _req(t, dtype, name):
 class PackedLinear:
     """nn.Linear weight [N,K] (+bias) re-tiled for the MFMA GEMM kernels."""
 
-    __slots__ = ("wp", "bias", "N", "K", "swiglu")
+    __slots__ = ("wp", "bias", "N", "K", "swiglu", "th")
 
-    def __init__(self, wp, bias, N, K, swiglu=False):
-        self.wp, self.bias, self.N, self.K, self.swiglu = wp, bias, N, K, swiglu
+    def __init__(self, wp, bias, N, K, swiglu=False, th=16):
+        self.wp, self.bias, self.N, self.K, self.swiglu, self.th = wp, bias, N, K, swiglu, th
+
+    def for_decode(self, n_cus=256):
+        """A second, decode-only image with th-row tiles such that the number of tiles is a multiple of the
+        CU count (exact partition of the weight stream over the chip); returns self when 16 is already fine."""
+        if self.swiglu or self.th != 16:
+            return self
+        best = None
+        for th in range(15, 7, -1):
+            if self.N % th == 0 and (self.N // th) % n_cus == 0:
+                best = th
+                break
+        if best is None or ((self.N + 15) // 16) % n_cus == 0:
+            return self
+        lib = _lib.load()
+        out = torch.empty(lib.umv_repacked_weight_elems(self.N, self.K, best), dtype=BF16, device=self.wp.device)
+        check(lib.umv_repack_weight_rows_bf16(_p(self.wp), _p(out), self.N, self.K, best, _stream()), "umv_repack_weight_rows_bf16")
+        return PackedLinear(out, self.bias, self.N, self.K, False, best)
 
     @staticmethod
     def from_weight(w, bias=None):
@@ -96,7 +113,7 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         out=out.data_ptr(), ldo=out.stride(0),
         row_idx=row_idx.data_ptr() if row_idx is not None else None,
         M=M, N=lin.N, K=lin.K, epilogue=flags,
-        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps)
+        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th)
     check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
     return out
 
@@ -145,6 +162,17 @@ def argmax(logits, out=None):
     M, V = logits.shape
     out = torch.empty((M,), dtype=torch.int64, device=logits.device) if out is None else out
     check(lib.umv_argmax_bf16(_p(logits), logits.stride(0), _p(out), M, V, _stream()), "umv_argmax_bf16")
+    return out
+
+
+def sample(logits, temperature, seed, step=None, out=None):
+    """multinomial(softmax(logits / temperature), 1) per row (device-side counter-based RNG)."""
+    lib = _lib.load()
+    _req(logits, BF16, "logits")
+    M, V = logits.shape
+    out = torch.empty((M,), dtype=torch.int64, device=logits.device) if out is None else out
+    check(lib.umv_sample_bf16(_p(logits), logits.stride(0), _p(out), M, V, float(temperature), int(seed) & (2 ** 64 - 1),
+                              _p(step), _stream()), "umv_sample_bf16")
     return out
 
 
