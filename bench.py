@@ -165,6 +165,8 @@ def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128,
     passes = int(sum(3 if (t > 0.4 and t <= 1.0) else 1 for t in ts.tolist()))
     return {"images_per_s": round(world * batch / el, 4), "unit": "images/s", "s_per_batch": round(el, 3), "batch_per_gpu": batch,
             "image": f"{hw}x{hw}", "num_timesteps": num_timesteps, "llm_passes_per_image": passes, "prompt_tokens": prompt_len,
+            "note": "reference schedule = 131 sequential passes/image; here the guided passes of a step run as one packed "
+                    "forward and the no-image pass (bit-identical context for pure T2I) reuses v_t: same arithmetic, 90 pass-equivalents",
             "cfg": "text 4.0, img 1.5, interval (0.4,1.0], renorm global, shift 3.0",
             "workload": "configs[2]: UniMedVL-14B text-to-image, 50 diffusion steps, 256x256, batch=4, incl. VAE decode"}
 

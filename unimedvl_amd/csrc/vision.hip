@@ -132,124 +132,179 @@ struct ConvGeom {
     int B, Cin, Hin, Win, Cout, Hout, Wout, ks, mode;
 };
 
-#define CV_BM 128
-#define CV_BN 128
-__global__ __launch_bounds__(256) void conv_tiled_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
-                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
-                                                         bf16_t* __restrict__ out, ConvGeom geo, int KT, int NTT, int mblocks) {
-    __shared__ __attribute__((aligned(16))) bf16_t xs[2][CV_BM / 16][64][8];
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_page_v[4] = {0, 0, 0, 0};
+typedef __attribute__((address_space(3))) void* lds_ptr_v;
+
+// Same pipeline as gemm_tiled_kernel (gemm.hip): WN x WM waves of TN x TM MFMA tiles, k-step KTS*32, NBUF LDS
+// buffers filled by LDS-DMA with counted vmcnt and one raw barrier per step.  W tiles are straight 1 KiB copies
+// of the packed image; an x tile is the im2col fragment gathered per lane (tap / channel decode per k, zero page
+// for padding, upsampled or strided source coordinates by mode).
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
+__global__ __launch_bounds__(WN * WM * 64) void conv_tiled_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                                  bf16_t* __restrict__ out, ConvGeom geo, int KT, int NTT, int mblocks) {
+    constexpr int NW = WN * WM;
+    constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+    constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;
+    constexpr int TPW = (WTILES + XTILES) / NW;
+    static_assert((WTILES + XTILES) % NW == 0, "staging tiles must divide evenly over the waves");
+    constexpr int BUF = (WTILES + XTILES) * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int wn = wave & 1, wm = wave >> 1;
+    const int wn = wave % WN, wm = wave / WN;
     const int mblk = blockIdx.x % mblocks;
     const int nblk = blockIdx.x / mblocks;
-    const int m0 = mblk * CV_BM;
-    const int nt_base = nblk * (CV_BN / 16) + wn * 4;
+    const int m0 = mblk * BM;
+    const int nt_blk = nblk * (BN / 16);
+    const int nt_base = nt_blk + wn * TN;
     const int M = geo.B * geo.Hout * geo.Wout;
     const int K = geo.ks * geo.ks * geo.Cin;
+    const int nsteps = (KT + KTS - 1) / KTS;
 
-    // staging role: fragment f = tid + i*256 -> (m-tile, lane)
-    int sb[2], soy[2], sox[2], skg[2];
-    bool svalid[2];
+    // per staged tile: either a W tile (pointer) or an x tile (this lane's output pixel)
+    const bf16_t* wsrc[TPW];
+    bool wvalid[TPW];
+    int pb[TPW], poy[TPW], pox[TPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = tid + i * 256;
-        int mt = f >> 6, l = f & 63;
-        int m = m0 + mt * 16 + (l & 15);
-        svalid[i] = m < M;
-        int mm = svalid[i] ? m : 0;
-        sb[i] = mm / (geo.Hout * geo.Wout);
-        int rem = mm % (geo.Hout * geo.Wout);
-        soy[i] = rem / geo.Wout;
-        sox[i] = rem % geo.Wout;
-        skg[i] = (l >> 4) * 8;
-    }
-    auto gather = [&](int i, int kt) -> bf16x8 {
-        const int k = kt * 32 + skg[i];
-        if (!svalid[i] || k >= K) return zero_frag();
-        const int tap = k / geo.Cin, ci = k % geo.Cin;
-        const int ky = tap / geo.ks, kx = tap % geo.ks;
-        int iy, ix;
-        if (geo.mode == 0) {
-            const int pad = (geo.ks - 1) >> 1;
-            iy = soy[i] + ky - pad; ix = sox[i] + kx - pad;
-            if (iy < 0 || iy >= geo.Hin || ix < 0 || ix >= geo.Win) return zero_frag();
-        } else if (geo.mode == 1) {
-            iy = soy[i] + ky - 1; ix = sox[i] + kx - 1;       // coordinates in the 2x upsampled image
-            if (iy < 0 || iy >= 2 * geo.Hin || ix < 0 || ix >= 2 * geo.Win) return zero_frag();
-            iy >>= 1; ix >>= 1;
+    for (int i = 0; i < TPW; ++i) {
+        const int f = wave * TPW + i;
+        wsrc[i] = nullptr; wvalid[i] = false; pb[i] = poy[i] = pox[i] = 0;
+        if (f < WTILES) {
+            const int tl = f / KTS, kk = f % KTS;
+            const int nt = nt_blk + tl;
+            wvalid[i] = nt < NTT;
+            wsrc[i] = wp + ((int64_t)(wvalid[i] ? nt : 0) * KT + kk) * 512 + lane * 8;
         } else {
-            iy = 2 * soy[i] + ky; ix = 2 * sox[i] + kx;       // zero pad on the bottom / right only
-            if (iy >= geo.Hin || ix >= geo.Win) return zero_frag();
+            const int tl = (f - WTILES) / KTS;
+            int m = m0 + tl * 16 + r;
+            m = m < M ? m : M - 1;
+            pb[i] = m / (geo.Hout * geo.Wout);
+            const int rem = m % (geo.Hout * geo.Wout);
+            poy[i] = rem / geo.Wout;
+            pox[i] = rem % geo.Wout;
         }
-        return ldg_frag(x + (((int64_t)sb[i] * geo.Hin + iy) * geo.Win + ix) * geo.Cin + ci);
-    };
-    const bf16_t* wbase[4];
-    bool tvalid[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        tvalid[t] = (nt_base + t) < NTT;
-        wbase[t] = wp + ((int64_t)(tvalid[t] ? nt_base + t : 0) * KT) * 512 + lane * 8;
     }
-    f32x4 acc[4][4];
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_v);
+    auto stage = [&](int step, int buf) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 stage[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) stage[i] = gather(i, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = tid + i * 256;
-        *reinterpret_cast<bf16x8*>(&xs[0][f >> 6][f & 63][0]) = stage[i];
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) stage[i] = gather(i, kt + 1);
-        }
-        bf16x8 wf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wf[t] = ldg_frag(wbase[t] + (int64_t)kt * 512);
-        bf16x8 xf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(&xs[cur][wm * 4 + j][lane][0]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int f = tid + i * 256;
-                *reinterpret_cast<bf16x8*>(&xs[cur ^ 1][f >> 6][f & 63][0]) = stage[i];
+        for (int i = 0; i < TPW; ++i) {
+            const int f = wave * TPW + i;
+            const bf16_t* p = zero;
+            if (f < WTILES) {
+                const int kt = step * KTS + f % KTS;
+                if (wvalid[i] && kt < KT) p = wsrc[i] + (int64_t)step * (KTS * 512);
+            } else {
+                const int kt = step * KTS + (f - WTILES) % KTS;
+                const int k = kt * 32 + g * 8;
+                if (k < K) {
+                    const int tap = k / geo.Cin, ci = k - tap * geo.Cin;
+                    const int ky = tap / geo.ks, kx = tap - ky * geo.ks;
+                    int iy, ix;
+                    bool ok;
+                    if (geo.mode == 0) {
+                        const int pad = (geo.ks - 1) >> 1;
+                        iy = poy[i] + ky - pad; ix = pox[i] + kx - pad;
+                        ok = iy >= 0 && iy < geo.Hin && ix >= 0 && ix < geo.Win;
+                    } else if (geo.mode == 1) {
+                        iy = poy[i] + ky - 1; ix = pox[i] + kx - 1;        // coordinates in the 2x upsampled image
+                        ok = iy >= 0 && iy < 2 * geo.Hin && ix >= 0 && ix < 2 * geo.Win;
+                        iy >>= 1; ix >>= 1;
+                    } else {
+                        iy = 2 * poy[i] + ky; ix = 2 * pox[i] + kx;        // zero pad on the bottom / right only
+                        ok = iy < geo.Hin && ix < geo.Win;
+                    }
+                    if (ok) p = x + (((int64_t)pb[i] * geo.Hin + iy) * geo.Win + ix) * geo.Cin + ci;
+                }
             }
+            char* dst = smem + buf * BUF + f * 1024;
+            __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_v)dst, 16, 0, 0);
         }
-        __syncthreads();
-    }
-    // epilogue: + bias -> bf16 ; (+ residual -> bf16)
+    };
+    f32x4 acc[TN][TM];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + (wm * 4 + j) * 16 + r;
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p)
+        if (p < nsteps) stage(p, p);
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step % NBUF;
+        const int ahead = min(NBUF - 2, nsteps - 1 - step);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
+        const char* wb = smem + cur * BUF;
+        const char* xb = wb + WTILES * 1024;
+#pragma unroll
+        for (int kk = 0; kk < KTS; ++kk) {
+            bf16x8 wf[TN], xf[TM];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + ((wn * TN + t) * KTS + kk) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + ((wm * TM + j) * KTS + kk) * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
+        }
+    }
+    // epilogue: + bias -> bf16 ; (+ residual -> bf16); 4 consecutive output channels per lane
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 16 + r;
         if (m >= M) continue;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TN; ++t) {
             const int n0 = (nt_base + t) * 16 + g * 4;
             if (n0 >= geo.Cout) continue;
-            float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
+            const float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
+            bf16_t o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (n0 + q >= geo.Cout) continue;
-                float o = rbf(v[q] + (bias ? bf2f(bias[n0 + q]) : 0.f));
-                if (residual) o = rbf(o + bf2f(residual[(int64_t)m * geo.Cout + n0 + q]));
-                out[(int64_t)m * geo.Cout + n0 + q] = f2bf(o);
+                const int n = min(n0 + q, geo.Cout - 1);
+                float f = rbf(v[q] + (bias ? bf2f(bias[n]) : 0.f));
+                if (residual) f = rbf(f + bf2f(residual[(int64_t)m * geo.Cout + n]));
+                o[q] = f2bf(f);
+            }
+            bf16_t* dst = out + (int64_t)m * geo.Cout + n0;
+            if (n0 + 3 < geo.Cout && (geo.Cout & 3) == 0) {
+                u32x2 pk;
+                pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                *reinterpret_cast<u32x2*>(dst) = pk;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n0 + q < geo.Cout) dst[q] = o[q];
             }
         }
     }
+}
+
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
+static int launch_conv(const bf16_t* x, const bf16_t* wp, const bf16_t* bias, const bf16_t* residual, bf16_t* out, const ConvGeom& geo,
+                       int KT, int NTT, hipStream_t s) {
+    constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+    constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int M = geo.B * geo.Hout * geo.Wout;
+    const int mblocks = (M + BM - 1) / BM, nblocks = (geo.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, x, wp, bias,
+                       residual, out, geo, KT, NTT, mblocks);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
 }
 
 extern "C" int umv_conv2d_nhwc_bf16(const uint16_t* x, const uint16_t* wp, const uint16_t* bias, const uint16_t* residual,
@@ -267,11 +322,11 @@ extern "C" int umv_conv2d_nhwc_bf16(const uint16_t* x, const uint16_t* wp, const
     if (M == 0) return UMV_OK;
     const int K = ksize * ksize * Cin;
     const int KT = (K + 31) / 32, NTT = (Cout + 15) / 16;
-    const int mblocks = (M + CV_BM - 1) / CV_BM, nblocks = (Cout + CV_BN - 1) / CV_BN;
-    hipLaunchKernelGGL(conv_tiled_kernel, dim3(mblocks * nblocks), dim3(256), 0, (hipStream_t)stream, x, wp, bias, residual, out,
-                       geo, KT, NTT, mblocks);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 16) return launch_conv<1, 4, 1, 4, 4, 2>(x, wp, bias, residual, out, geo, KT, NTT, s);     // conv_out: 16(n) x 256(m)
+    const long wg128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
+    if (wg128 >= 384) return launch_conv<2, 2, 4, 4, 2, 2>(x, wp, bias, residual, out, geo, KT, NTT, s);  // 128 x 128 x 64
+    return launch_conv<2, 2, 4, 2, 2, 3>(x, wp, bias, residual, out, geo, KT, NTT, s);                    // 128(n) x 64(m) x 64
 }
 
 // ----------------------------------------------------------------------------- VAE: GroupNorm(32) (+ swish), NHWC
