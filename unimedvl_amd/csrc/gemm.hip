@@ -453,7 +453,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //     s_barrier                         everyone's part of tile t landed AND everyone finished reading tile t-1
 //     issue LDS-DMA for tile t+NBUF-1   into the buffer tile t-1 just vacated
 //     ds_read fragments of tile t, MFMAs
-template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int PRIO = 0>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
@@ -530,6 +530,43 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
     for (int p = 0; p < NBUF - 1; ++p)
         if (p < nsteps) stage(p, p);
+    if constexpr (PRIO == 2) {
+        // Register double buffering (KTS == 1): the fragments of tile t+1 are read from LDS while the MFMAs of
+        // tile t run out of registers, so the matrix pipe does not wait for ds_read latency after each barrier.
+        static_assert(PRIO != 2 || (KTS == 1 && NBUF >= 3), "fragment double buffering needs KTS == 1 and >= 3 LDS buffers");
+        bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
+        auto ldfrag = [&](int buf, bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
+            const char* wb = smem + buf * BUF;
+            const char* xb = wb + WTILES * 1024;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + (wn * TN + t) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + (wm * TM + j) * 1024 + lane * 16);
+        };
+        auto wait_tiles = [&](int allowed) {   // tiles (of TPW DMA ops each) that may stay in flight
+            if (allowed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
+            else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        wait_tiles(min(NBUF - 2, nsteps - 1));
+        __builtin_amdgcn_s_barrier();
+        ldfrag(0, wfA, xfA);
+        auto body = [&](int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
+            const bool more = step + 1 < nsteps;
+            if (more) wait_tiles(min(NBUF - 3, nsteps - 2 - step));      // tile step+1 landed (mine)
+            __builtin_amdgcn_s_barrier();                                // ... everyone's; and tile step-1's buffer is free
+            if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
+            if (more) ldfrag((step + 1) % NBUF, wnx, xnx);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wc[t], xc[j], acc[t][j]);
+        };
+        for (int step = 0; step < nsteps; step += 2) {
+            body(step, wfA, xfA, wfB, xfB);
+            if (step + 1 < nsteps) body(step + 1, wfB, xfB, wfA, xfA);
+        }
+    } else
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step % NBUF;
         // tiles still allowed in flight behind tile `step`
@@ -548,10 +585,12 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + ((wn * TN + t) * KTS + kk) * 1024 + lane * 16);
 #pragma unroll
             for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + ((wm * TM + j) * KTS + kk) * 1024 + lane * 16);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
     // epilogue with compile-time accumulator indices (a runtime-indexed acc[][] would be demoted to scratch)
@@ -584,19 +623,19 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     });
 }
 
-template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int PRIO = 0>
 static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, PRIO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
+    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, PRIO>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
                        NTT, mblocks, nblocks);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
@@ -662,6 +701,10 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 128) return launch_tiled<2, 2, 4, 4, 2, 3>(a, KT, NTT, s);      // 128x128x64, 3 buffers (96 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
+    if (cfg == 260) return launch_tiled<2, 4, 8, 4, 2, 2>(a, KT, NTT, s);      // 256x256x64, 2 buffers (128 KiB)
+    if (cfg == 261) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, setprio around the MFMAs
+    if (cfg == 263) return launch_tiled<2, 4, 8, 4, 1, 4, 2>(a, KT, NTT, s);   // 256x256x32, 4 buffers, fragment double buffering
+    if (cfg == 262) return launch_tiled<2, 4, 8, 4, 1, 3>(a, KT, NTT, s);      // 256x256x32, 3 buffers (96 KiB)
     if (cfg == 257) return launch_tiled<2, 4, 8, 2, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves, 4 buffers (96 KiB)
     if (cfg == 258) return launch_tiled<4, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves as 4x2 (96 KiB)
     if (cfg == 259) return launch_tiled<2, 4, 4, 4, 1, 4>(a, KT, NTT, s);      // 128(n)x256(m)x32, 8 waves (96 KiB)

@@ -43,6 +43,16 @@ class Qwen2MoT:
         self.w = weights
         self.device = device
         self.decode_nsplit = 8
+        import os
+        # measured on MI355X: no gain (2.03 vs 2.02 img/s) - the 256x256 GEMM's 8 waves x 166 VGPRs + 128 KiB LDS
+        # leave no room for the skinny GEMM to co-reside - so the two-stream variant is off by default
+        self.overlap_experts = os.environ.get("UMV_OVERLAP_EXPERTS", "0") not in ("0", "")
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # ------------------------------------------------------------------ embeddings / head
     def embed_tokens(self, ids, out=None, out_rows=None):
@@ -114,11 +124,24 @@ class Qwen2MoT:
         if seq.data_ptr() == packed_query_sequence.data_ptr():
             seq = seq.clone()   # residual stream is updated in place; never clobber the caller's tensor
 
+        # MoT routing: the few text rows stream the `und` expert's weights (HBM-bound skinny GEMM) while the latent
+        # rows run the `gen` expert's MFMA-bound tiled GEMM.  They touch disjoint rows, so with overlap_experts the
+        # two launch on different streams and share the chip instead of running back to back.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if (gen and self.overlap_experts) else None
+
         def routed(xin, und_lin, gen_lin, out, residual=None):
             if not gen:
                 return ops.gemm(xin, und_lin, out=out, residual=residual)
-            ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual)
+            if side is None:
+                ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual)
+                ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual)
+                return out
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual)
             ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual)
+            main.wait_stream(side)
             return out
 
         for l in range(cfg.layers):
