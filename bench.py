@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the whole run on e4m3 LLM weights (BASELINE.json configs[4]); the headline value is the bf16 run")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weights decode leg of the default run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -213,6 +216,7 @@ def main():
         from oracle.weights import TINY
         cfg = UniMedVLConfig.from_dict(TINY)
         img_hw, prompt_len = 56, 8
+    cfg.llm_weight_dtype = args.weights
     B = args.batch
     t_load = time.time()
     want_t2i = not args.no_t2i
@@ -220,57 +224,64 @@ def main():
     torch.cuda.synchronize()
     t_load = time.time() - t_load
 
-    # ---- prefill: ViT encode + LLM prefill of the image span, then the question
     new_token_ids = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2,
                          end_of_image=cfg.vocab - 1)
     g = torch.Generator().manual_seed(1234 + rank)
     hi = min(150000, cfg.vocab - 8)
     prompts = [torch.randint(min(1000, hi // 2), hi, (prompt_len,), generator=g).tolist() for _ in range(B)]
     images = [synth_image(img_hw, img_hw, 1000 * rank + i) for i in range(B)]
-    cache = NaiveCache(cfg.layers)
-    kvl, rope = [0] * B, [0] * B
-    t0 = time.time()
-    gi, kvl, rope = model.prepare_vit_images(kvl, rope, images, lambda x: x, new_token_ids)
-    cache.reserve(B, max(kvl) + prompt_len + 2 + args.steps + args.warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
-    cache = model.forward_cache_update_vit(cache, **gi)
-    gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), new_token_ids)
-    cache = model.forward_cache_update_text(cache, **gi)
-    torch.cuda.synchronize()
-    t_prefill = time.time() - t0
-    ctx = kvl[0]
 
-    # ---- decode
-    gi = model.prepare_start_tokens(kvl, rope, new_token_ids)
-    total = args.warmup + args.steps
-    sess = DecodeSession(model.language_model, cache, gi["packed_start_tokens"], gi["packed_query_position_ids"],
-                         total + 1, use_graph=not args.no_graph)
-    sess.step(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    sess.step(args.steps)
-    ids_local = sess.pred_ids[args.warmup:args.warmup + args.steps]
-    if dist is not None:   # C1: the only collective - gather every rank's generated ids over xGMI
-        gathered = [torch.empty_like(ids_local) for _ in range(world)]
-        dist.all_gather(gathered, ids_local.contiguous())
-    e1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    gpu_ms = e0.elapsed_time(e1)
-    sess.commit()
-    toks = ids_local.cpu()
-    assert toks.shape == (args.steps, B) and int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab
+    def decode_leg(model):
+        # ---- prefill: ViT encode + LLM prefill of the image span, then the question
+        cache = NaiveCache(cfg.layers)
+        kvl, rope = [0] * B, [0] * B
+        t0 = time.time()
+        gi, kvl, rope = model.prepare_vit_images(kvl, rope, images, lambda x: x, new_token_ids)
+        cache.reserve(B, max(kvl) + prompt_len + 2 + args.steps + args.warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
+        cache = model.forward_cache_update_vit(cache, **gi)
+        gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), new_token_ids)
+        cache = model.forward_cache_update_text(cache, **gi)
+        torch.cuda.synchronize()
+        t_prefill = time.time() - t0
+        ctx = kvl[0]
+
+        # ---- decode
+        gi = model.prepare_start_tokens(kvl, rope, new_token_ids)
+        total = args.warmup + args.steps
+        sess = DecodeSession(model.language_model, cache, gi["packed_start_tokens"], gi["packed_query_position_ids"],
+                             total + 1, use_graph=not args.no_graph)
+        sess.step(args.warmup)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        sess.step(args.steps)
+        ids_local = sess.pred_ids[args.warmup:args.warmup + args.steps]
+        if dist is not None:   # C1: the only collective - gather every rank's generated ids over xGMI
+            gathered = [torch.empty_like(ids_local) for _ in range(world)]
+            dist.all_gather(gathered, ids_local.contiguous())
+        e1.record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        gpu_ms = e0.elapsed_time(e1)
+        sess.commit()
+        toks = ids_local.cpu()
+        assert toks.shape == (args.steps, B) and int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab
+
+        return dict(sess=sess, cache=cache, elapsed=elapsed, gpu_ms=gpu_ms, ctx=ctx, t_prefill=t_prefill)
+
+    leg = decode_leg(model)
+    sess, cache, elapsed, gpu_ms, ctx, t_prefill = (leg[k] for k in ("sess", "cache", "elapsed", "gpu_ms", "ctx", "t_prefill"))
 
     # ---- roofline of the dominant kernel: the weight-streaming skinny GEMM (gemm_skinny_kernel<1,2>:
     # the 28 gate/up SwiGLU projections + lm_head of one step), HIP events on the launch stream
@@ -295,8 +306,9 @@ def main():
     launches = reps * (cfg.layers + 1)
     avg_us = k0.elapsed_time(k1) * 1e3 / launches
     # algorithmic bytes per launch: packed bf16 weight once + x + out
-    gu_bytes = 2 * cfg.inter * cfg.hidden * 2 + B * cfg.hidden * 2 + B * cfg.inter * 2
-    lm_bytes = cfg.vocab * cfg.hidden * 2 + B * cfg.hidden * 2 + B * cfg.vocab * 2
+    wb = 1 if lw.fp8 else 2    # bytes per streamed weight (fp8 adds 4 bytes of scale per output channel)
+    gu_bytes = 2 * cfg.inter * cfg.hidden * wb + B * cfg.hidden * 2 + B * cfg.inter * 2 + (8 * cfg.inter if lw.fp8 else 0)
+    lm_bytes = cfg.vocab * cfg.hidden * wb + B * cfg.hidden * 2 + B * cfg.vocab * 2 + (4 * cfg.vocab if lw.fp8 else 0)
     bytes_per_launch = (cfg.layers * gu_bytes + lm_bytes) / (cfg.layers + 1)
     achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
     # whole-step algorithmic bytes (weights + KV read/write + logits), for the step-level fraction
@@ -342,15 +354,16 @@ def main():
         "metric": "VQA greedy decode tokens/s, UniMedVL-14B (BAGEL-7B-MoT dims), batch 8 x 448x448 per GPU",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (random N(0,0.02^2) weights at assumed 14B dims, synthetic images, random token ids)",
-        "config": {"workload": "configs[1]: UniMedVL-14B bf16 VQA greedy decode, batch=8 448x448, 1xMI355X"
+        "dtype": "bf16" if not lw.fp8 else "bf16 (e4m3 weights, power-of-two channel scales)", "data": "synthetic (random N(0,0.02^2) weights at assumed 14B dims, synthetic images, random token ids)",
+        "config": {"workload": ("configs[1]: UniMedVL-14B bf16 VQA greedy decode, batch=8 448x448, 1xMI355X" if not lw.fp8 else
+                                "configs[4]-style: UniMedVL-14B fp8-weight VQA greedy decode, batch=8 448x448 per GPU")
                                if args.config == "full" else "tiny smoke config",
                    "batch_per_gpu": B, "context_tokens": ctx, "image": f"{img_hw}x{img_hw}", "prompt_tokens": prompt_len,
                    "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                    "prefill_s": round(t_prefill, 3), "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "gemm_skinny_kernel<1,2> (28 gate/up SwiGLU GEMMs + lm_head per step)",
+                     "kernel": ("gemm_skinny8_kernel<1,2,4>" if lw.fp8 else "gemm_skinny_kernel<1,2>") + " (28 gate/up SwiGLU GEMMs + lm_head per step)",
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                      "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
@@ -364,6 +377,32 @@ def main():
             out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, num_timesteps=args.t2i_steps)
         else:
             out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, batch=2, hw=64, prompt_len=8, num_timesteps=6)
+    if not args.no_fp8 and not lw.fp8 and args.config == "full":
+        # extra leg (BASELINE.json configs[4]): the same workload on e4m3 LLM weights; never the headline value
+        del model, lw
+        try:
+            del sess, cache
+        except NameError:
+            pass
+        leg = None
+        torch.cuda.empty_cache()
+        cfg8 = UniMedVLConfig.from_dict(cfg.to_dict())
+        cfg8.llm_weight_dtype = "fp8"
+        model8 = Bagel(cfg8, random_getter(cfg8, dev, seed=1234), device=dev, visual_gen=False, visual_und=True)
+        l8 = decode_leg(model8)
+        w8 = model8.language_model.w
+        ms8 = l8["elapsed"] * 1e3 / args.steps
+        sb8 = w8.decode_weight_bytes() + B * (l8["ctx"] + args.warmup + args.steps / 2) * kv_tok + B * kv_tok + B * cfg.vocab * 2
+        out["decode_fp8_weights"] = {
+            "tokens_per_s": round(world * B * args.steps / l8["elapsed"], 2), "ms_per_step": round(ms8, 4),
+            "weights": "OCP e4m3, one power-of-two scale per output channel; bf16 activations, fp32 accumulate",
+            "weight_bytes_per_step": int(w8.decode_weight_bytes()),
+            "step_algorithmic_GBps": round(sb8 / (ms8 * 1e-3) / 1e9, 1),
+            "step_frac_of_peak": round(sb8 / (ms8 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "workload": "configs[4]-style: same batch / context as the headline run, fp8 weights",
+            "parity": "bit-identical to the bf16 kernels run on the dequantised weights (tests/test_fp8_gpu.py)"}
+        del model8, l8
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
         try:
             out["cpu_baseline"] = cpu_baseline(B, ctx, cfg.layers)

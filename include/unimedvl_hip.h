@@ -79,8 +79,46 @@ typedef struct {
     float norm_eps;
     int tile_rows;            /* rows per n-tile of `wp`: 0 or 16 = umv_pack_weight_bf16 image; 1..15 = an image made by
                                  umv_repack_weight_rows_bf16 (decode only, M <= 64) */
+    const float* w_scale;     /* umv_gemm_fp8w only: per-channel scales written by umv_quantize_pack_weight_fp8 */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
+
+/* ------------------------------------------------------------------ fp8 weights (BASELINE.json configs[4]; no
+ * reference counterpart: the reference only has bf16 weights, qwen2_navit.py:541-562 / modeling_qwen2.py:229-235)
+ * Weight-only OCP e4m3 with one POWER-OF-TWO scale per output channel, s[n] = the smallest 2^e with
+ * 448 * 2^e >= max_k |W[n,k]|, q = rne_e4m3(W / s).  W' = q * s is exact in bf16, so
+ *   umv_gemm_fp8w(x, q, s)  ==  umv_gemm_bf16(x, pack(W'))   bit for bit   (K % 512 == 0)
+ * and prefill / diffusion (M > 64) run umv_gemm_bf16 on the bf16 image of W' while decode streams half the bytes.
+ * Image: P8[n/16][k/64][lane = ((k%32)/8)*16 + n%16][(k%64)/32][k%8] bytes, zero padded; `scale` is f32
+ * [ceil(N/16)*16] in image row order.  With w_up != NULL, `w`/`w_up` are gate_proj / up_proj [rows=I, K] and the
+ * image interleaves their 16-row tiles (UMV_EPI_SWIGLU).  deq / deq_up (optional) receive W' row-major. */
+size_t umv_packed_weight_fp8_bytes(int N, int K);
+int umv_quantize_pack_weight_fp8(const uint16_t* w, const uint16_t* w_up, uint8_t* packed8, float* scale, uint16_t* deq,
+                                 uint16_t* deq_up, int rows, int K, umv_stream_t stream);
+/* M <= 64 only; a->wp = the e4m3 image, a->w_scale = its scales; norm_w / tile_rows unsupported */
+int umv_gemm_fp8w(const umv_gemm_args* a, umv_stream_t stream);
+
+/* ------------------------------------------------------------------ decode GEMM (M <= 16; Bagel.generate_text,
+ * bagel.py:1262-1314 -> the F.linear calls of one-token-per-sample steps: qwen2_navit.py:541-543,617-620,
+ * modeling_qwen2.py:234-235, bagel.py:1295).  One persistent workgroup per CU streams ONE contiguous slab of a
+ * "decode image": workgroup w owns output channels [w*C, (w+1)*C), C = ceil(rows/G), as tpw tiles of th <= 16 rows,
+ *   bf16: D[w][tile][k/32][(k%32)/8][r < th][k%8]     e4m3: D8[w][tile][k/64][(k%32)/8][r < th][(k%64)/32][k%8]
+ * (SwiGLU: every tile is a (gate, up) pair; rows = I).  x - optionally Qwen2RMSNorm(x)*norm_w, fused - is fetched once
+ * per workgroup.  Same K split and summation order as umv_gemm_bf16 / umv_gemm_fp8w at M <= 16: bit-identical results. */
+typedef struct {
+    int G;   /* workgroups = slabs (the CU count of the device: 256 on MI355X) */
+    int C;   /* channels per slab */
+    int th;  /* rows per tile */
+    int tpw; /* tiles per slab (the last one may be ragged) */
+} umv_decode_layout;
+int umv_decode_layout_for(int rows, int G, umv_decode_layout* out);
+size_t umv_decode_image_bytes(int K, int swiglu, int fp8, const umv_decode_layout* L);
+/* packed16: the standard image (umv_pack_weight_bf16 / _swiglu_bf16, or the e4m3 image with scale16 = its scales);
+ * scale_out: f32 [G*tpw*(swiglu?2:1)*16] (e4m3 only) */
+int umv_repack_weight_decode(const void* packed16, const float* scale16, void* out, float* scale_out, int rows, int K,
+                             int swiglu, int fp8, const umv_decode_layout* L, umv_stream_t stream);
+/* a->wp = decode image (a->w_scale = its scales when fp8); a->tile_rows is ignored; a->norm_w needs K <= 4096 */
+int umv_gemm_decode(const umv_gemm_args* a, const umv_decode_layout* L, int fp8, umv_stream_t stream);
 
 /* ------------------------------------------------------------------ norms / elementwise */
 /* Qwen2RMSNorm (modeling_qwen2.py:89-94): out = w * bf16(x * rsqrt(mean(x^2)+eps)).

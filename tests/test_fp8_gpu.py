@@ -1,0 +1,173 @@
+"""fp8 weight path (BASELINE.json configs[4]) on the GPU, through the C ABI:
+  * umv_quantize_pack_weight_fp8 == oracle/fp8.py bit for bit (codes, scales, dequantised weights);
+  * umv_gemm_fp8w == umv_gemm_bf16 on the dequantised weights, bit for bit (K % 512 == 0: same K slices);
+  * the engine with llm_weight_dtype="fp8" against the CPU oracle run on the dequantised weights, at the bf16
+    path's tolerances (logits atol 0.25 / cosine > 0.999, greedy ids exact outside near-ties).
+There is no reference fp8 path; see oracle/fp8.py."""
+import pytest
+import torch
+
+from conftest import NEW_TOKEN_IDS
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from unimedvl_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("N,K", [(48, 512), (100, 200), (256, 1024)])
+def test_quantize_matches_oracle(N, K):
+    ops = _ops()
+    from oracle import fp8
+    g = torch.Generator().manual_seed(N * 7 + K)
+    w = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, 1, generator=g) * 2) * 0.02).to(BF16)
+    w[3] = 0
+    w[7, 5] = 2.0 ** -40   # far below the channel scale: flushes to an e4m3 subnormal / zero
+    lin = ops.PackedLinear.from_weight_fp8(w.cuda())
+    q, scale, deq = fp8.quantize_rows(w)
+    assert torch.equal(lin.scale.cpu()[:N], scale)
+    assert torch.equal(fp8.unpack_image(lin.w8, N, K), q)
+    # the bf16 image carried for M > 64 is the packed image of exactly W'
+    ref = ops.PackedLinear.from_weight(deq.cuda())
+    assert torch.equal(lin.wp.cpu(), ref.wp.cpu())
+
+
+def test_quantize_all_codes():
+    ops = _ops()
+    codes = torch.arange(256, dtype=torch.uint8)
+    vals = codes.view(torch.float8_e4m3fn).to(torch.float32)
+    finite = ~torch.isnan(vals)
+    row = torch.cat([vals[finite], torch.tensor([448.0])]).to(BF16)
+    w = torch.zeros(16, 256, dtype=BF16)
+    w[0, :row.numel()] = row
+    lin = ops.PackedLinear.from_weight_fp8(w.cuda())
+    from oracle import fp8
+    q = fp8.unpack_image(lin.w8, 16, 256)
+    got = q[0, :row.numel() - 1].view(torch.float8_e4m3fn).to(torch.float32)
+    assert torch.equal(got, vals[finite]), "device e4m3 conversion is OCP e4m3fn, round to nearest even"
+    # and the device's fp8 -> bf16 conversion inverts it for every code (through the GEMM: x = one-hot rows)
+    x = torch.zeros(16, 256, dtype=BF16)
+    for i in range(16):
+        x[i, i] = 1.0
+    out = ops.gemm(x.cuda(), lin)
+    assert torch.equal(out[:, 0].float().cpu(), row[:16].float())
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 17, 40, 64])
+@pytest.mark.parametrize("N,K,swiglu", [(4608, 3584, False), (1024, 512, True), (3584, 18944, False), (320, 1536, False)])
+def test_gemm_fp8w_bit_exact_vs_bf16_on_dequantised(M, N, K, swiglu):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    x = torch.randn(M, K, generator=g).to(BF16).cuda()
+    if swiglu:
+        gate = (torch.randn(N // 2, K, generator=g) * 0.05).to(BF16).cuda()
+        up = (torch.randn(N // 2, K, generator=g) * 0.05).to(BF16).cuda()
+        lin8 = ops.PackedLinear.from_gate_up_fp8(gate, up)
+        bias = None
+    else:
+        w = (torch.randn(N, K, generator=g) * 0.05).to(BF16).cuda()
+        bias = torch.randn(N, generator=g).to(BF16).cuda()
+        lin8 = ops.PackedLinear.from_weight_fp8(w, bias)
+    assert lin8.w8.numel() == ((N + 15) // 16) * ((K + 63) // 64) * 1024   # one byte per (padded) weight
+    lin16 = ops.PackedLinear(lin8.wp, lin8.bias, lin8.N, lin8.K, lin8.swiglu)   # bf16 image of W', no fp8 image
+    res = None if swiglu else torch.randn(M, N, generator=g).to(BF16).cuda()
+    got = ops.gemm(x, lin8, residual=res)
+    ref = ops.gemm(x, lin16, residual=res)
+    assert torch.equal(got, ref)
+    # row-indexed (MoT text rows) variant
+    if not swiglu and M >= 8:
+        idx = torch.randperm(M, generator=g)[: M // 2].to(torch.int32).cuda()
+        o1 = torch.zeros(M, N, dtype=BF16, device="cuda")
+        o2 = torch.zeros(M, N, dtype=BF16, device="cuda")
+        ops.gemm(x, lin8, out=o1, M=idx.numel(), row_idx=idx)
+        ops.gemm(x, lin16, out=o2, M=idx.numel(), row_idx=idx)
+        assert torch.equal(o1, o2)
+
+
+def test_gemm_fp8w_rejects_large_m():
+    ops = _ops()
+    from unimedvl_amd import _lib
+    from unimedvl_amd._lib import GemmArgs
+    import ctypes as C
+    lin = ops.PackedLinear.from_weight_fp8(torch.randn(64, 128).to(BF16).cuda())
+    x = torch.randn(128, 128).to(BF16).cuda()
+    out = torch.empty(128, 64, dtype=BF16, device="cuda")
+    a = GemmArgs(x=x.data_ptr(), ldx=128, wp=lin.w8.data_ptr(), out=out.data_ptr(), ldo=64, M=128, N=64, K=128,
+                 w_scale=lin.scale.data_ptr())
+    lib = _lib.load()
+    assert lib.umv_gemm_fp8w(C.byref(a), None) != 0
+    assert b"M <= 64" in lib.umv_last_error()
+    # ops.gemm routes M > 64 to the bf16 image of the dequantised weights instead
+    lin16 = ops.PackedLinear(lin.wp, None, lin.N, lin.K)
+    assert torch.equal(ops.gemm(x, lin), ops.gemm(x, lin16))
+
+
+@pytest.fixture(scope="module")
+def engine_fp8(tiny_weights):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    cfg, sd, _, _ = tiny_weights
+    c = UniMedVLConfig.from_dict(cfg)
+    c.llm_weight_dtype = "fp8"
+    return Bagel(c, lambda n: sd[n], device="cuda")
+
+
+def test_engine_fp8_vqa_matches_oracle_on_dequantised_weights(engine_fp8, tiny_weights):
+    from oracle import fp8
+    from oracle.unimedvl_cpu import OracleBagel, KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    cfg, sd, vae_sd, _ = tiny_weights
+    model = engine_fp8
+    assert model.language_model.w.fp8 and model.language_model.w.und[0].qkv.w8 is not None
+    g = torch.Generator().manual_seed(11)
+    imgs = [torch.randn(3, 42, 56, generator=g).clamp(-1, 1), torch.randn(3, 28, 70, generator=g).clamp(-1, 1)]
+    prompts = [[11, 22, 33, 44], [55, 66, 77]]
+
+    class Tok:
+        def __init__(self):
+            self.i = 0
+
+        def encode(self, s):
+            return prompts[int(s)]
+
+    cache = NaiveCache(cfg["layers"])
+    gi, kvl, rope = model.prepare_vit_images([0, 0], [0, 0], imgs, lambda x: x, NEW_TOKEN_IDS)
+    cache = model.forward_cache_update_vit(cache, **gi)
+    gi, kvl, rope = model.prepare_prompts(kvl, rope, ["0", "1"], Tok(), NEW_TOKEN_IDS)
+    cache = model.forward_cache_update_text(cache, **gi)
+    gi = model.prepare_start_tokens(kvl, rope, NEW_TOKEN_IDS)
+    ids, logits = model.generate_text(past_key_values=cache, max_length=5, return_logits=True, **gi)
+
+    o = OracleBagel(cfg, fp8.dequantised_weights(sd), vae_sd, attn_impl="sdpa")
+    oc = KVCache(cfg["layers"], 2)
+    okv, orope = o.update_vit(oc, [0, 0], [0, 0], imgs, NEW_TOKEN_IDS)
+    bos, eos = NEW_TOKEN_IDS["bos_token_id"], NEW_TOKEN_IDS["eos_token_id"]
+    okv, orope = o.update_text(oc, okv, orope, [[bos] + p + [eos] for p in prompts])
+    oids, ologits = o.generate_text(oc, orope, bos, 5, return_logits=True)
+    assert okv == kvl and orope == rope
+    lg, rl = logits.float().cpu(), ologits.float()
+    for s in range(5):
+        assert torch.equal(ids[s].cpu(), oids[s]), f"fed token differs at step {s}"
+        d = (lg[s] - rl[s]).abs().max().item()
+        assert d <= 0.25, f"logits differ by {d} at step {s}"
+        cos = torch.nn.functional.cosine_similarity(lg[s].flatten(), rl[s].flatten(), dim=0).item()
+        assert cos > 0.999
+        top2 = rl[s].topk(2, dim=-1).values
+        sure = (top2[:, 0] - top2[:, 1]) > 0.25
+        assert torch.equal(lg[s].argmax(-1)[sure], rl[s].argmax(-1)[sure])
+        if not torch.equal(lg[s].argmax(-1), rl[s].argmax(-1)):
+            break
+    # quantisation is not a no-op: the bf16 oracle's logits differ visibly from the fp8 model's
+    o16 = OracleBagel(cfg, sd, vae_sd, attn_impl="sdpa")
+    oc16 = KVCache(cfg["layers"], 2)
+    k16, r16 = o16.update_vit(oc16, [0, 0], [0, 0], imgs, NEW_TOKEN_IDS)
+    k16, r16 = o16.update_text(oc16, k16, r16, [[bos] + p + [eos] for p in prompts])
+    _, l16 = o16.generate_text(oc16, r16, bos, 1, return_logits=True)
+    assert (l16[0].float() - rl[0]).abs().max().item() > 1e-3

@@ -19,8 +19,12 @@ class GemmArgs(C.Structure):
         ("x", C.c_void_p), ("ldx", C.c_int64), ("wp", C.c_void_p), ("bias", C.c_void_p),
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
         ("row_idx", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
-        ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("tile_rows", C.c_int),
+        ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("tile_rows", C.c_int), ("w_scale", C.c_void_p),
     ]
+
+
+class DecodeLayout(C.Structure):
+    _fields_ = [("G", C.c_int), ("C", C.c_int), ("th", C.c_int), ("tpw", C.c_int)]
 
 
 class QkvPostArgs(C.Structure):
@@ -66,6 +70,15 @@ _SIGS = {
     "umv_repack_weight_rows_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "umv_pack_weight_swiglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "umv_packed_weight_fp8_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "umv_quantize_pack_weight_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_void_p]),
+    "umv_gemm_fp8w": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "umv_decode_layout_for": (C.c_int, [C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
+    "umv_decode_image_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
+    "umv_repack_weight_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(DecodeLayout), C.c_void_p]),
+    "umv_gemm_decode": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(DecodeLayout), C.c_int, C.c_void_p]),
     "umv_rmsnorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_float, C.c_void_p]),
     "umv_layernorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,

@@ -19,6 +19,9 @@ class UniMedVLConfig:
     rope_theta: float = 1e6
     rms_eps: float = 1e-6
     max_position: int = 32768
+    # "bf16" (the reference's precision) or "fp8": weight-only e4m3 with power-of-two channel scales for the LLM
+    # linear layers and lm_head (BASELINE.json configs[4]; include/unimedvl_hip.h umv_quantize_pack_weight_fp8)
+    llm_weight_dtype: str = "bf16"
     # SigLIP NaViT (the scripts drop the last layer: interactive_vqa_inferencer.py:213)
     vit_hidden: int = 1152
     vit_layers: int = 26

@@ -16,7 +16,7 @@
 //     4 waves of 64x64, W fragments from the packed stream, x staged through LDS.
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
-#include <type_traits>
+#include "gemm_epilogue.h"
 #include <stdlib.h>
 
 // ----------------------------------------------------------------------------- packing
@@ -113,101 +113,6 @@ extern "C" int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t*
     return UMV_OK;
 }
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-
-// ----------------------------------------------------------------------------- epilogue math
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
-    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-    const float kKappa = 0.044715f;
-    float x3 = x * x * x;
-    float inner = kBeta * (x + kKappa * x3);
-    return 0.5f * x * (1.0f + tanhf(inner));
-}
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
-
-struct EpiCtx {
-    const bf16_t* bias;
-    const bf16_t* residual;
-    int64_t ldr;
-    void* out;
-    int64_t ldo;
-    int N;       // logical N of the GEMM (2I for swiglu)
-    int flags;
-};
-
-// Finish 4 consecutive n (n0..n0+3) of row `orow` from fp32 accumulators.
-__device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0, float v0, float v1, float v2, float v3) {
-    float v[4] = {v0, v1, v2, v3};
-    if (e.flags & UMV_EPI_BIAS) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < e.N) v[j] += bf2f(e.bias[n0 + j]);
-    }
-    if (e.flags & UMV_EPI_OUT_F32) {
-        float* o = reinterpret_cast<float*>(e.out) + orow * e.ldo + n0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < e.N) o[j] = v[j];
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = rbf(v[j]);
-    if (e.flags & UMV_EPI_GELU_TANH) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rbf(gelu_tanh_f(v[j]));
-    }
-    if (e.flags & UMV_EPI_SILU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rbf(silu_f(v[j]));
-    }
-    if (e.flags & UMV_EPI_RESIDUAL) {
-        const bf16_t* rr = e.residual + orow * e.ldr + n0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < e.N) v[j] = rbf(v[j] + bf2f(rr[j]));
-    }
-    bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + n0;
-    if (n0 + 3 < e.N && ((e.ldo & 3) == 0)) {
-        u32x2 pk;
-        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<u32x2*>(o) = pk;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < e.N) o[j] = f2bf(v[j]);
-    }
-}
-
-// SwiGLU: g,u accumulators of the same 4 output columns -> act[orow][c0..c0+3]
-__device__ __forceinline__ void epi_swiglu4(const EpiCtx& e, int64_t orow, int c0, int I, const float* g, const float* u) {
-    bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + c0;
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float gg = rbf(g[j]), uu = rbf(u[j]);
-        v[j] = rbf(rbf(silu_f(gg)) * uu);   // act_fn(gate) -> bf16, * up -> bf16 (modeling_qwen2.py:235)
-    }
-    if (c0 + 3 < I && ((e.ldo & 3) == 0)) {
-        u32x2 pk;
-        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<u32x2*>(o) = pk;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c0 + j < I) o[j] = f2bf(v[j]);
-    }
-}
-
 // ----------------------------------------------------------------------------- skinny (M <= 64)
 // Weight streaming, HBM-bound.  One workgroup = NT n-tiles x all of K; its 8 waves take
 // contiguous K slices and reduce through LDS.  Each wave keeps U weight fragments per n-tile
@@ -217,7 +122,7 @@ __device__ __forceinline__ void epi_swiglu4(const EpiCtx& e, int64_t orow, int c
 // the row sum of squares is combined across waves through LDS, and the fragments are
 // normalised in place with the reference's two bf16 roundings before feeding the MFMAs.
 #define SK_WAVES 8
-#define SK_XMAX 16   // NORM: k-tiles of x a wave can hold (K <= 8*16*32 = 4096)
+#define SK_XMAX 16   // NORM: K <= 8*16*32 = 4096
 
 template <int MB, int NT, int U>
 struct SkBuf {
@@ -225,7 +130,7 @@ struct SkBuf {
     bf16x8 x[U][MB];
 };
 
-template <int MB, int NT, int U, bool DB, bool NORM>
+template <int MB, int NT, int U, bool DB, int NORM>   // NORM: 0 = off, 8 / 16 = fused RMSNorm keeping that many x rows
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_args a, int KT, int NTT) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [SK_WAVES][NT*MB*4][64] (+ norm partials)
     const int tid = threadIdx.x;
@@ -283,55 +188,68 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
     SkBuf<MB, NT, U> b0, b1;
     if (nchunks > 0) load_chunk(0, b0);
 
-    if constexpr (NORM) {
+    if constexpr (NORM != 0) {
         static_assert(!NORM || MB == 1, "fused RMSNorm supports M <= 16");
         // Stage RMSNorm(x) * norm_w ONCE per workgroup into LDS, already in MFMA B-fragment order:
         // slot (kt, g, r) holds the 8 bf16 of row r at k = kt*32 + g*8.  MP = rows kept (8 or 16).
-        const int MP = a.M <= 8 ? 8 : 16;
+        constexpr int MP = NORM ? NORM : 8;
         bf16_t* xl = reinterpret_cast<bf16_t*>(red + SK_WAVES * NT * MB * 4 * 64 + SK_WAVES * 16);
         float* part = red + SK_WAVES * NT * MB * 4 * 64;   // [SK_WAVES][16]
         const int rr = tid & (MP - 1);
-        const int per_kt = 4 * MP;
-        const int nslots = KT * per_kt;
+        constexpr int sh = MP == 8 ? 3 : 4;        // log2(MP)
+        constexpr int XS = MP;                     // 16-byte groups per thread: (4096/32) * 4 * MP / 512
+        const int nslots = KT * 4 * MP;
         const bool rowok = rr < a.M;
         const bf16_t* xr = a.x + (rowok ? (a.row_idx ? (int64_t)a.row_idx[rr] : (int64_t)rr) : 0) * a.ldx;
-        // pass 1: row sums of squares (x is tiny and L2 resident; it is re-read in pass 2 rather than
-        // held in registers, which keeps the kernel at 2 workgroups per CU)
-        float ss = 0.f;
-        for (int sidx = tid; sidx < nslots; sidx += SK_WAVES * 64) {
-            const int kt = sidx / per_kt, gg = (sidx % per_kt) / MP;
-            const int k = kt * 32 + gg * 8;
-            if (rowok && k < a.K) {
-                bf16x8 v = ldg_frag(xr + k);
+        // ONE batch of loads per phase: a loop of dependent L2 round trips (7 per pass at K = 3584) costs ~10 us per
+        // workgroup, a batch about one round trip.  Phase 1: x -> registers -> row sums of squares, raw x parked in LDS.
+        {
+            bf16x8 xv[XS];
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
+                const int sidx = tid + i * SK_WAVES * 64;
+                const int k = (sidx >> (sh + 2)) * 32 + ((sidx >> sh) & 3) * 8;
+                xv[i] = (sidx < nslots && k < a.K && rowok) ? ldg_frag(xr + k) : zero_frag();
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float f = bf2f((bf16_t)v[j]);
+                    float f = bf2f((bf16_t)xv[i][j]);
                     ss += f * f;
                 }
+                const int sidx = tid + i * SK_WAVES * 64;
+                if (sidx < nslots) *reinterpret_cast<bf16x8*>(xl + (int64_t)sidx * 8) = xv[i];
             }
+            // lanes sharing a row: lane & (MP-1)
+            if (MP == 8) ss += __shfl_xor(ss, 8, 64);
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (lane < MP) part[wave * 16 + lane] = ss;
         }
-        // lanes sharing a row: lane & (MP-1)
-        if (MP == 8) ss += __shfl_xor(ss, 8, 64);
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        if (lane < MP) part[wave * 16 + lane] = ss;
+        // phase 2: norm_w batch (in flight across the barrier), then normalise the thread's own slots in place
+        bf16x8 wv[XS];
+#pragma unroll
+        for (int i = 0; i < XS; ++i) {
+            const int sidx = tid + i * SK_WAVES * 64;
+            const int k = (sidx >> (sh + 2)) * 32 + ((sidx >> sh) & 3) * 8;
+            wv[i] = (sidx < nslots && k < a.K) ? ldg_frag(a.norm_w + k) : zero_frag();
+        }
         __syncthreads();
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < SK_WAVES; ++w) tot += part[w * 16 + rr];
         const float rstd = rsqrt_ieee(tot / (float)a.K + a.norm_eps);
-        // pass 2: normalise with the reference's two bf16 roundings and store fragments
-        for (int sidx = tid; sidx < nslots; sidx += SK_WAVES * 64) {
-            const int kt = sidx / per_kt, gg = (sidx % per_kt) / MP;
-            const int k = kt * 32 + gg * 8;
-            bf16x8 o = zero_frag();
-            if (rowok && k < a.K) {
-                bf16x8 v = ldg_frag(xr + k);
-                bf16x8 wn = ldg_frag(a.norm_w + k);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bf2f((bf16_t)wn[j]) * rbf(bf2f((bf16_t)v[j]) * rstd));
+        for (int i = 0; i < XS; ++i) {
+            const int sidx = tid + i * SK_WAVES * 64;
+            if (sidx < nslots) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(xl + (int64_t)sidx * 8), o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bf2f((bf16_t)wv[i][j]) * rbf(bf2f((bf16_t)v[j]) * rstd));   // two roundings
+                *reinterpret_cast<bf16x8*>(xl + (int64_t)sidx * 8) = o;
             }
-            *reinterpret_cast<bf16x8*>(xl + (int64_t)sidx * 8) = o;
         }
         __syncthreads();
         const int rsel = r & (MP - 1);
@@ -433,6 +351,287 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
             }
         }
     }
+}
+
+// ----------------------------------------------------------------------------- fp8 weights (decode, BASELINE.json configs[4])
+// Weight-only e4m3 (OCP) with one power-of-two scale per output channel (an E8M0 exponent, as in the MX
+// formats): W' = q * 2^e is exactly representable in bf16, so streaming q and converting in registers
+// (v_cvt_scalef32_pk_bf16_fp8: two elements per instruction, the channel scale rides along for free) feeds the
+// SAME bf16 MFMAs with the SAME operands as the bf16 kernel on W'.  Decode reads half the bytes; prefill /
+// diffusion keep using the bf16 image of W' on the tiled kernel, and both paths agree bit for bit.
+//   image: P8[nt][kt8][lane][16 B], lane = g*16 + r; bytes 0..7  <-> W[nt*16 + r][kt8*64 +      g*8 + j]
+//                                                    bytes 8..15 <-> W[nt*16 + r][kt8*64 + 32 + g*8 + j]
+//   scale: f32 [ntt*16] in packed row order (SwiGLU images interleave gate / up 16-row tiles like the bf16 one)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+
+__device__ __forceinline__ void cvt_fp8x16(u32x4 q, float scale, bf16x8& lo, bf16x8& hi) {
+    union { bf16x2_hw h[4]; bf16x8 v; } a, b;
+    a.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, false);
+    a.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, true);
+    a.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, false);
+    a.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, true);
+    b.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.z, scale, false);
+    b.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.z, scale, true);
+    b.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.w, scale, false);
+    b.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.w, scale, true);
+    lo = a.v;
+    hi = b.v;
+}
+
+// smallest power of two s with 448 * s >= amax (448 = 0.875 * 2^9 is the largest finite e4m3 value)
+__device__ __forceinline__ float fp8_pow2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.0f;
+    int ea;
+    float ma = frexpf(amax, &ea);   // amax = ma * 2^ea, ma in [0.5, 1)
+    return ldexpf(1.0f, ma <= 0.875f ? ea - 9 : ea - 8);
+}
+
+// One workgroup (256 threads) per packed 16-row tile: row maxima -> scales -> e4m3 image (+ optional W' in bf16).
+__global__ __launch_bounds__(256) void quantize_pack_fp8_kernel(const bf16_t* __restrict__ w, const bf16_t* __restrict__ w2,
+                                                                uint8_t* __restrict__ p8, float* __restrict__ scale,
+                                                                bf16_t* __restrict__ deq, bf16_t* __restrict__ deq2, int rows,
+                                                                int K, int KT8) {
+    __shared__ float smax[16][17];
+    __shared__ float sscale[16];
+    const int nt = blockIdx.x, tid = threadIdx.x;
+    const bool inter = w2 != nullptr;
+    const bf16_t* src = (inter && (nt & 1)) ? w2 : w;
+    bf16_t* dq = (inter && (nt & 1)) ? deq2 : deq;
+    const int row0 = (inter ? (nt >> 1) : nt) * 16;
+    {   // 16 threads per row
+        const int r = tid >> 4, c = tid & 15;
+        float m = 0.f;
+        if (row0 + r < rows)
+            for (int k = c; k < K; k += 16) m = fmaxf(m, fabsf(bf2f(src[(int64_t)(row0 + r) * K + k])));
+        smax[r][c] = m;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float m = 0.f;
+        for (int c = 0; c < 16; ++c) m = fmaxf(m, smax[tid][c]);
+        const float s = fp8_pow2_scale(m);
+        sscale[tid] = s;
+        scale[nt * 16 + tid] = s;
+    }
+    __syncthreads();
+    // one thread per (kt8, lane) 16-byte group
+    for (int idx = tid; idx < KT8 * 64; idx += 256) {
+        const int lane = idx & 63, kt8 = idx >> 6;
+        const int r = lane & 15, g = lane >> 4;
+        const bool rowok = row0 + r < rows;
+        const float inv = 1.0f / sscale[r];   // exact: a power of two
+        uint32_t o[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k0 = kt8 * 64 + h * 32 + g * 8;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (rowok && k0 + j < K) ? bf2f(src[(int64_t)(row0 + r) * K + k0 + j]) * inv : 0.f;
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+            o[2 * h] = (uint32_t)lo;
+            o[2 * h + 1] = (uint32_t)hi;
+            if (dq && rowok) {
+                u32x4 qq = {(uint32_t)lo, (uint32_t)hi, 0u, 0u};
+                bf16x8 d, unused;
+                cvt_fp8x16(qq, sscale[r], d, unused);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k0 + j < K) dq[(int64_t)(row0 + r) * K + k0 + j] = (bf16_t)d[j];
+            }
+        }
+        u32x4 v = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<u32x4*>(p8 + ((int64_t)nt * KT8 * 64 + idx) * 16) = v;
+    }
+}
+
+extern "C" size_t umv_packed_weight_fp8_bytes(int N, int K) {
+    return ((size_t)(N + 15) / 16) * ((size_t)(K + 63) / 64) * 1024;
+}
+
+extern "C" int umv_quantize_pack_weight_fp8(const uint16_t* w, const uint16_t* w_up, uint8_t* packed8, float* scale,
+                                            uint16_t* deq, uint16_t* deq_up, int rows, int K, umv_stream_t stream) {
+    UMV_CHECK(w && packed8 && scale && rows > 0 && K > 0, UMV_ERR_ARG, "quantize_pack_weight_fp8: bad args");
+    UMV_CHECK(!w_up || (rows % 16) == 0, UMV_ERR_ARG, "quantize_pack_weight_fp8: SwiGLU image needs I %% 16 == 0 (I=%d)", rows);
+    UMV_CHECK(!(deq_up && !w_up), UMV_ERR_ARG, "quantize_pack_weight_fp8: deq_up without w_up");
+    const int ntt = (w_up ? 2 : 1) * ((rows + 15) / 16), KT8 = (K + 63) / 64;
+    hipLaunchKernelGGL(quantize_pack_fp8_kernel, dim3(ntt), dim3(256), 0, (hipStream_t)stream, w, w_up, packed8, scale, deq, deq_up,
+                       rows, K, KT8);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+template <int MB, int NT, int U>
+struct SkBuf8 {
+    u32x4 w[U][NT];
+    bf16x8 x[U][2][MB];
+};
+
+// Same work decomposition as gemm_skinny_kernel (8 waves split K in contiguous slices, LDS reduce in wave
+// order), over 64-wide k super-tiles; for K % 512 == 0 the slices - and so the fp32 sums - are identical.
+template <int MB, int NT, int U>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_args a, int KT8, int NTT) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int nt0 = blockIdx.x * NT;
+    const uint8_t* wq = reinterpret_cast<const uint8_t*>(a.wp);
+
+    const bf16_t* xrow[MB];
+    bool xvalid[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        int m = mb * 16 + r;
+        xvalid[mb] = m < a.M;
+        int64_t row = xvalid[mb] ? (a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m) : 0;
+        xrow[mb] = a.x + row * a.ldx;
+    }
+    f32x4 acc[NT][MB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int kt_per = (KT8 + SK_WAVES - 1) / SK_WAVES;
+    const int kt_begin = wave * kt_per;
+    const int kt_end = min(KT8, kt_begin + kt_per);
+    const int nk = max(0, kt_end - kt_begin);
+    const int nchunks = (nk + U - 1) / U;
+    const uint8_t* wbase[NT];
+    float wscale[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bool tv = (nt0 + t) < NTT;
+        const int nt = tv ? nt0 + t : 0;
+        wbase[t] = wq + ((int64_t)nt * KT8 * 64 + lane) * 16;
+        wscale[t] = a.w_scale[nt * 16 + r];
+    }
+    // x costs as much L2->L1 traffic as the e4m3 weights at NT = 1 (M = 8 rows x 2 B vs 16 rows x 1 B per k) and is what
+    // holds this kernel below the HBM rate: down_proj 18.2 us with these x loads, 12.8 us with x from a constant
+    // (tools/skinny_bench.py; rotating the K order per workgroup or pre-packing x in fragment order did not help).
+    auto load_chunk = [&](int c, SkBuf8<MB, NT, U>& b) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt_begin + c * U + u;
+            const bool ok = kt < kt_end;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                b.w[u][t] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase[t] + (int64_t)kt * 1024)) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = kt * 64 + h * 32 + g * 8;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) b.x[u][h][mb] = (ok && xvalid[mb] && k < a.K) ? ldg_frag(xrow[mb] + k) : zero_frag();
+            }
+        }
+    };
+    auto consume = [&](SkBuf8<MB, NT, U>& b) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8 wlo[NT], whi[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cvt_fp8x16(b.w[u][t], wscale[t], wlo[t], whi[t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(wlo[t], b.x[u][0][mb], acc[t][mb]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(whi[t], b.x[u][1][mb], acc[t][mb]);
+        }
+    };
+    SkBuf8<MB, NT, U> b0, b1;
+    if (nchunks > 0) load_chunk(0, b0);
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 1 < nchunks) load_chunk(c + 1, b1);
+        consume(b0);
+        if (c + 1 < nchunks) {
+            if (c + 2 < nchunks) load_chunk(c + 2, b0);
+            consume(b1);
+        }
+    }
+    // cross-wave reduction + epilogue: identical to gemm_skinny_kernel (16-row tiles)
+    constexpr int E4 = NT * MB;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) reinterpret_cast<f32x4*>(red)[(wave * E4 + t * MB + mb) * 64 + lane] = acc[t][mb];
+    __syncthreads();
+    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    if (a.epilogue & UMV_EPI_SWIGLU) {
+        for (int idx = tid; idx < (NT / 2) * MB * 64; idx += SK_WAVES * 64) {
+            int l = idx & 63;
+            int f = idx >> 6;
+            int pair = f / MB, mb = f % MB;
+            f32x4 sg = {0, 0, 0, 0}, su = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) {
+                sg += reinterpret_cast<f32x4*>(red)[(w * E4 + (2 * pair) * MB + mb) * 64 + l];
+                su += reinterpret_cast<f32x4*>(red)[(w * E4 + (2 * pair + 1) * MB + mb) * 64 + l];
+            }
+            int m = mb * 16 + (l & 15);
+            int ntile = nt0 + 2 * pair;
+            if (m < a.M && ntile < NTT) {
+                int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+                int c0 = (ntile >> 1) * 16 + (l >> 4) * 4;
+                float gg[4] = {sg.x, sg.y, sg.z, sg.w}, uu[4] = {su.x, su.y, su.z, su.w};
+                epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < E4 * 64; idx += SK_WAVES * 64) {
+            int l = idx & 63;
+            int f = idx >> 6;
+            int t = f / MB, mb = f % MB;
+            f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) s += reinterpret_cast<f32x4*>(red)[(w * E4 + f) * 64 + l];
+            int m = mb * 16 + (l & 15);
+            int n0 = (nt0 + t) * 16 + (l >> 4) * 4;
+            if (m < a.M && n0 < a.N) {
+                int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+                epi_store4(e, orow, n0, s.x, s.y, s.z, s.w);
+            }
+        }
+    }
+}
+
+template <int MB, int NT, int U>
+static int launch_skinny8(const umv_gemm_args& a, int KT8, int NTT, hipStream_t s) {
+    int blocks = (NTT + NT - 1) / NT;
+    size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
+    hipLaunchKernelGGL((gemm_skinny8_kernel<MB, NT, U>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT8, NTT);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+extern "C" int umv_gemm_fp8w(const umv_gemm_args* ap, umv_stream_t stream) {
+    UMV_CHECK(ap != nullptr, UMV_ERR_ARG, "gemm_fp8w: null args");
+    umv_gemm_args a = *ap;
+    UMV_CHECK(a.x && a.wp && a.out && a.w_scale, UMV_ERR_ARG, "gemm_fp8w: null pointer (x, wp, out and w_scale are required)");
+    UMV_CHECK(a.M >= 0 && a.N > 0 && a.K > 0, UMV_ERR_ARG, "gemm_fp8w: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    UMV_CHECK(a.M <= 64, UMV_ERR_UNSUPPORTED, "gemm_fp8w: the e4m3 image is the decode (M <= 64) layout; use the bf16 image of the "
+              "dequantised weights with umv_gemm_bf16 for M=%d", a.M);
+    UMV_CHECK((a.K % 8) == 0 && (a.ldx % 8) == 0, UMV_ERR_ARG, "gemm_fp8w: K (%d) and ldx (%lld) must be multiples of 8", a.K,
+              (long long)a.ldx);
+    UMV_CHECK(!(a.epilogue & UMV_EPI_BIAS) || a.bias, UMV_ERR_ARG, "gemm_fp8w: BIAS without bias pointer");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_RESIDUAL) || a.residual, UMV_ERR_ARG, "gemm_fp8w: RESIDUAL without residual pointer");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm_fp8w: SWIGLU needs N %% 32 == 0");
+    UMV_CHECK(!a.norm_w && (a.tile_rows == 0 || a.tile_rows == 16), UMV_ERR_UNSUPPORTED, "gemm_fp8w: no fused norm / th-row tiles");
+    if (a.M == 0) return UMV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int KT8 = (a.K + 63) / 64, NTT = (a.N + 15) / 16;
+    const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
+    // (NT, U) from a sweep on MI355X at M = 8 (tools/skinny_bench.py, FP8=1): gate/up 25.5 us with <2,2> (110 VGPRs, two
+    // workgroups per CU) vs 33.9 <2,4>, 27.9 <4,1>; down_proj 18.2 us with <1,8> vs 23.7 for NT = 2 (only 112 workgroups)
+    if (a.M <= 16) return two ? launch_skinny8<1, 2, 2>(a, KT8, NTT, s) : launch_skinny8<1, 1, 8>(a, KT8, NTT, s);
+    if (a.M <= 32) return two ? launch_skinny8<2, 2, 2>(a, KT8, NTT, s) : launch_skinny8<2, 1, 4>(a, KT8, NTT, s);
+    return two ? launch_skinny8<4, 2, 1>(a, KT8, NTT, s) : launch_skinny8<4, 1, 2>(a, KT8, NTT, s);
 }
 
 // ----------------------------------------------------------------------------- tiled (M > 64)
@@ -641,11 +840,11 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     return UMV_OK;
 }
 
-template <int MB, int NT, int U, bool DB, bool NORM>
+template <int MB, int NT, int U, bool DB, int NORM>
 static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     int blocks = (NTT + NT - 1) / NT;
     size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
-    if (NORM) lds += SK_WAVES * 16 * sizeof(float) + (size_t)KT * 4 * (a.M <= 8 ? 8 : 16) * 16;
+    if (NORM) lds += SK_WAVES * 16 * sizeof(float) + (size_t)KT * 4 * NORM * 16;
     hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT, NTT);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
@@ -674,11 +873,12 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (a.M <= 64) {
         const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
         if (a.M <= 16) {
-            if (a.norm_w) return two ? launch_skinny<1, 2, 4, true, true>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, true>(a, KT, NTT, s);
-            return two ? launch_skinny<1, 2, 4, true, false>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, false>(a, KT, NTT, s);
+            if (a.norm_w && a.M <= 8) return two ? launch_skinny<1, 2, 4, true, 8>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, 8>(a, KT, NTT, s);
+            if (a.norm_w) return two ? launch_skinny<1, 2, 4, true, 16>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, 16>(a, KT, NTT, s);
+            return two ? launch_skinny<1, 2, 4, true, 0>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, 0>(a, KT, NTT, s);
         }
-        if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, false>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, false>(a, KT, NTT, s);
-        return two ? launch_skinny<4, 2, 2, false, false>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, false>(a, KT, NTT, s);
+        if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
+        return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
     // Tile choice from measurements on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 256x256x32
     // 4-buffer tile wins whenever it yields about one workgroup per CU and K is long enough to amortise its

@@ -51,10 +51,15 @@ class DecodeSession:
         self.act = torch.empty((B, cfg.inter), dtype=BF16, device=dev)
         self.hn = torch.empty((B, H), dtype=BF16, device=dev)
         self.logits = torch.empty((B, cfg.vocab), dtype=BF16, device=dev)
-        # RMSNorm can fold into the following GEMM's prologue (norm_w argument of umv_gemm_bf16), but on
-        # MI355X the per-workgroup normalise+stage prologue costs more than it saves at B=8
-        # (gate/up 47 -> 74 us, qkv 12 -> 22 us vs 57 x ~5 us of standalone norms), so it is off by default.
-        self.fuse_norm = fuse_norm and B <= 16 and H <= 4096
+        # RMSNorm can fold into the following GEMM's prologue (norm_w argument of umv_gemm_bf16), but on MI355X the
+        # per-workgroup normalise+stage prologue costs more than the ~5 us standalone norm it replaces at B=8, even with
+        # its loads batched into one round trip (qkv 11.2 -> 19.0 us, gate/up 42.7 -> 61.7 us, step 3.40 -> 3.93 ms): the
+        # x / norm_w loads queue behind the first weight chunk and every workgroup pays an HBM latency before its first
+        # MFMA.  The persistent variant (umv_gemm_decode, prologue once per CU) narrows it to +4..6 us per GEMM - still no
+        # gain - so fusion stays off by default (UMV_DECODE_FUSE_NORM=1 to experiment).
+        import os
+        fuse_norm = os.environ.get("UMV_DECODE_FUSE_NORM", "1" if fuse_norm else "0") not in ("0", "")
+        self.fuse_norm = fuse_norm and B <= 16 and H <= 4096 and not llm.w.fp8
         # Experimental (OFF): weight prefetch into the Infinity Cache on a parallel graph branch during the
         # latency-bound kernels (window sizes in MiB).  Measured on MI355X: the branch does not overlap with the
         # main chain under hipGraph replay and the step gets SLOWER (3.43 -> 4.5-5.4 ms), so it stays disabled;

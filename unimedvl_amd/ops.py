@@ -31,15 +31,49 @@ def _req(t, dtype, name):
 class PackedLinear:
     """nn.Linear weight [N,K] (+bias) re-tiled for the MFMA GEMM kernels."""
 
-    __slots__ = ("wp", "bias", "N", "K", "swiglu", "th")
+    __slots__ = ("wp", "bias", "N", "K", "swiglu", "th", "w8", "scale")
 
-    def __init__(self, wp, bias, N, K, swiglu=False, th=16):
+    def __init__(self, wp, bias, N, K, swiglu=False, th=16, w8=None, scale=None):
         self.wp, self.bias, self.N, self.K, self.swiglu, self.th = wp, bias, N, K, swiglu, th
+        # fp8 weights (BASELINE.json configs[4]): w8 = e4m3 image streamed by the decode GEMM (M <= 64), scale = its
+        # power-of-two channel scales; wp is then the bf16 image of the SAME dequantised weights for M > 64
+        self.w8, self.scale = w8, scale
+
+    @staticmethod
+    def from_weight_fp8(w, bias=None):
+        """Quantise an nn.Linear weight to e4m3 with power-of-two channel scales; see include/unimedvl_hip.h."""
+        lib = _lib.load()
+        w = _req(w.contiguous(), BF16, "weight")
+        N, K = w.shape
+        w8 = torch.empty(lib.umv_packed_weight_fp8_bytes(N, K), dtype=torch.uint8, device=w.device)
+        scale = torch.empty(((N + 15) // 16) * 16, dtype=torch.float32, device=w.device)
+        deq = torch.empty_like(w)
+        check(lib.umv_quantize_pack_weight_fp8(_p(w), None, _p(w8), _p(scale), _p(deq), None, N, K, _stream()),
+              "umv_quantize_pack_weight_fp8")
+        lin = PackedLinear.from_weight(deq, bias)
+        lin.w8, lin.scale = w8, scale
+        return lin
+
+    @staticmethod
+    def from_gate_up_fp8(gate, up):
+        lib = _lib.load()
+        gate = _req(gate.contiguous(), BF16, "gate")
+        up = _req(up.contiguous(), BF16, "up")
+        I, K = gate.shape
+        assert I % 16 == 0, "intermediate size must be a multiple of 16"
+        w8 = torch.empty(lib.umv_packed_weight_fp8_bytes(2 * I, K), dtype=torch.uint8, device=gate.device)
+        scale = torch.empty(2 * I, dtype=torch.float32, device=gate.device)
+        dg, du = torch.empty_like(gate), torch.empty_like(up)
+        check(lib.umv_quantize_pack_weight_fp8(_p(gate), _p(up), _p(w8), _p(scale), _p(dg), _p(du), I, K, _stream()),
+              "umv_quantize_pack_weight_fp8")
+        lin = PackedLinear.from_gate_up(dg, du)
+        lin.w8, lin.scale = w8, scale
+        return lin
 
     def for_decode(self, n_cus=256):
         """A second, decode-only image with th-row tiles such that the number of tiles is a multiple of the
         CU count (exact partition of the weight stream over the chip); returns self when 16 is already fine."""
-        if self.swiglu or self.th != 16:
+        if self.swiglu or self.th != 16 or self.w8 is not None:
             return self
         best = None
         for th in range(15, 7, -1):
@@ -77,6 +111,68 @@ class PackedLinear:
         return self.wp.numel() * 2
 
 
+class DecodeLinear:
+    """Decode image of a PackedLinear (include/unimedvl_hip.h "decode GEMM"): one contiguous slab of th-row tiles per
+    CU for the persistent M <= 16 weight-streaming kernel.  Built once per weight; e4m3 when the source has an fp8 image."""
+
+    __slots__ = ("wd", "scale", "bias", "N", "K", "swiglu", "fp8", "layout")
+
+    def __init__(self, lin, n_cus=None):
+        lib = _lib.load()
+        dev = (lin.w8 if lin.w8 is not None else lin.wp).device
+        if n_cus is None:
+            n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if lin.th != 16:
+            raise _lib.UmvError("DecodeLinear needs the standard 16-row image")
+        self.N, self.K, self.swiglu, self.bias = lin.N, lin.K, lin.swiglu, lin.bias
+        self.fp8 = lin.w8 is not None
+        rows = lin.N // 2 if lin.swiglu else lin.N
+        self.layout = _lib.DecodeLayout()
+        check(lib.umv_decode_layout_for(rows, n_cus, C.byref(self.layout)), "umv_decode_layout_for")
+        nbytes = lib.umv_decode_image_bytes(lin.K, int(lin.swiglu), int(self.fp8), C.byref(self.layout))
+        self.wd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L = self.layout
+        self.scale = torch.empty(L.G * L.tpw * (2 if lin.swiglu else 1) * 16, dtype=torch.float32, device=dev) if self.fp8 else None
+        src = lin.w8 if self.fp8 else lin.wp
+        check(lib.umv_repack_weight_decode(_p(src), _p(lin.scale) if self.fp8 else None, _p(self.wd), _p(self.scale), rows, lin.K,
+                                           int(lin.swiglu), int(self.fp8), C.byref(self.layout), _stream()), "umv_repack_weight_decode")
+
+    def nbytes(self):
+        return self.wd.numel()
+
+
+def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_bias=True, norm_w=None, norm_eps=1e-6):
+    """out = epilogue(x @ W^T) for M <= 16 rows from a DecodeLinear; norm_w fuses Qwen2RMSNorm(x) * norm_w (K <= 4096).
+    Bit-identical to gemm() on the same weight."""
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    assert x.stride(-1) == 1
+    M = x.shape[0] if M is None else M
+    flags = 0
+    if dlin.bias is not None and use_bias:
+        flags |= EPI_BIAS
+    if dlin.swiglu:
+        flags |= EPI_SWIGLU
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+    n_out = dlin.N // 2 if dlin.swiglu else dlin.N
+    if out is None:
+        assert row_idx is None, "row-indexed GEMM writes into a caller-provided buffer"
+        out = torch.empty((x.shape[0], n_out), dtype=BF16, device=x.device)
+    a = GemmArgs(
+        x=x.data_ptr(), ldx=x.stride(0), wp=dlin.wd.data_ptr(),
+        bias=dlin.bias.data_ptr() if (flags & EPI_BIAS) else None,
+        residual=residual.data_ptr() if residual is not None else None,
+        ldr=residual.stride(0) if residual is not None else 0,
+        out=out.data_ptr(), ldo=out.stride(0),
+        row_idx=row_idx.data_ptr() if row_idx is not None else None,
+        M=M, N=dlin.N, K=dlin.K, epilogue=flags,
+        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=0,
+        w_scale=dlin.scale.data_ptr() if dlin.fp8 else None)
+    check(lib.umv_gemm_decode(C.byref(a), C.byref(dlin.layout), int(dlin.fp8), _stream()), "umv_gemm_decode")
+    return out
+
+
 def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
          norm_w=None, norm_eps=1e-6):
     """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
@@ -105,6 +201,18 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
     if out is None:
         assert row_idx is None, "row-indexed GEMM writes into a caller-provided buffer"
         out = torch.empty((rows_out, n_out), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    if lin.w8 is not None and M <= 64 and norm_w is None:
+        a = GemmArgs(
+            x=x.data_ptr(), ldx=x.stride(0), wp=lin.w8.data_ptr(),
+            bias=lin.bias.data_ptr() if (flags & EPI_BIAS) else None,
+            residual=residual.data_ptr() if residual is not None else None,
+            ldr=residual.stride(0) if residual is not None else 0,
+            out=out.data_ptr(), ldo=out.stride(0),
+            row_idx=row_idx.data_ptr() if row_idx is not None else None,
+            M=M, N=lin.N, K=lin.K, epilogue=flags, norm_w=None, norm_eps=norm_eps, tile_rows=0,
+            w_scale=lin.scale.data_ptr())
+        check(lib.umv_gemm_fp8w(C.byref(a), _stream()), "umv_gemm_fp8w")
+        return out
     a = GemmArgs(
         x=x.data_ptr(), ldx=x.stride(0), wp=lin.wp.data_ptr(),
         bias=lin.bias.data_ptr() if (flags & EPI_BIAS) else None,

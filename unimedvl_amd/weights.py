@@ -24,10 +24,10 @@ def _dev(t, device):
     return t.to(device=device, dtype=BF16).contiguous()
 
 
-def _linear(get, device, wname, bname=None):
+def _linear(get, device, wname, bname=None, fp8=False):
     w = _dev(get(wname), device)
     b = _dev(get(bname), device) if bname else None
-    return ops.PackedLinear.from_weight(w, b)
+    return ops.PackedLinear.from_weight_fp8(w, b) if fp8 else ops.PackedLinear.from_weight(w, b)
 
 
 class LLMWeights:
@@ -35,14 +35,17 @@ class LLMWeights:
 
     def __init__(self, cfg: UniMedVLConfig, get, device, load_gen=True):
         p = "language_model.model."
+        if cfg.llm_weight_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"llm_weight_dtype must be 'bf16' or 'fp8', got {cfg.llm_weight_dtype!r}")
+        fp8 = self.fp8 = cfg.llm_weight_dtype == "fp8"
         self.embed = _dev(get(p + "embed_tokens.weight"), device)
         self.und, self.gen = [], []
         for l in range(cfg.layers):
-            self.und.append(self._layer(get, device, p + f"layers.{l}.", ""))
-            self.gen.append(self._layer(get, device, p + f"layers.{l}.", "_moe_gen") if load_gen else None)
+            self.und.append(self._layer(get, device, p + f"layers.{l}.", "", fp8))
+            self.gen.append(self._layer(get, device, p + f"layers.{l}.", "_moe_gen", fp8) if load_gen else None)
         self.norm = _dev(get(p + "norm.weight"), device)
         self.norm_gen = _dev(get(p + "norm_moe_gen.weight"), device) if load_gen else None
-        self.lm_head = _linear(get, device, "language_model.lm_head.weight")
+        self.lm_head = _linear(get, device, "language_model.lm_head.weight", fp8=fp8)
         # rotary tables exactly as Qwen2RotaryEmbedding returns them (modeling_qwen2.py:164-184):
         # fp32 outer product, cos/sin, cast to bf16; built on the CPU so the bits match torch's.
         hd = cfg.head_dim
@@ -54,19 +57,19 @@ class LLMWeights:
         self.sin = emb.sin().to(BF16).to(device)
 
     @staticmethod
-    def _layer(get, device, p, suf):
+    def _layer(get, device, p, suf, fp8=False):
         lw = LayerWeights()
         a = p + "self_attn."
         w = torch.cat([_dev(get(a + f"{n}_proj{suf}.weight"), device) for n in "qkv"], 0)
         b = torch.cat([_dev(get(a + f"{n}_proj{suf}.bias"), device) for n in "qkv"], 0)
-        lw.qkv = ops.PackedLinear.from_weight(w, b)
+        lw.qkv = ops.PackedLinear.from_weight_fp8(w, b) if fp8 else ops.PackedLinear.from_weight(w, b)
         del w
-        lw.o = _linear(get, device, a + f"o_proj{suf}.weight")
+        lw.o = _linear(get, device, a + f"o_proj{suf}.weight", fp8=fp8)
         g = _dev(get(p + f"mlp{suf}.gate_proj.weight"), device)
         u = _dev(get(p + f"mlp{suf}.up_proj.weight"), device)
-        lw.gate_up = ops.PackedLinear.from_gate_up(g, u)
+        lw.gate_up = ops.PackedLinear.from_gate_up_fp8(g, u) if fp8 else ops.PackedLinear.from_gate_up(g, u)
         del g, u
-        lw.down = _linear(get, device, p + f"mlp{suf}.down_proj.weight")
+        lw.down = _linear(get, device, p + f"mlp{suf}.down_proj.weight", fp8=fp8)
         lw.in_norm = _dev(get(p + f"input_layernorm{suf}.weight"), device)
         lw.post_norm = _dev(get(p + f"post_attention_layernorm{suf}.weight"), device)
         lw.q_norm = _dev(get(a + f"q_norm{suf}.weight"), device)
@@ -74,9 +77,11 @@ class LLMWeights:
         return lw
 
     def decode_weight_bytes(self):
-        n = self.lm_head.nbytes()
+        """bytes one decode step streams: the e4m3 images when llm_weight_dtype == "fp8", else the bf16 ones"""
+        nb = (lambda lin: lin.w8.numel()) if self.fp8 else (lambda lin: lin.nbytes())
+        n = nb(self.lm_head)
         for lw in self.und:
-            n += lw.qkv.nbytes() + lw.o.nbytes() + lw.gate_up.nbytes() + lw.down.nbytes()
+            n += nb(lw.qkv) + nb(lw.o) + nb(lw.gate_up) + nb(lw.down)
         return n
 
 
