@@ -870,7 +870,9 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(TH == 16 || (a.M <= 64 && !(a.epilogue & UMV_EPI_SWIGLU)), UMV_ERR_UNSUPPORTED,
               "gemm: %d-row packed tiles are a decode-only layout (M <= 64, no SwiGLU)", TH);
     const int NTT = (a.N + TH - 1) / TH;
-    if (a.M <= 64) {
+    static int skinny_max = -1;   // tuning only: UMV_GEMM_SKINNY_MAX=<M> (rows up to which the weight-streaming kernel is used)
+    if (skinny_max < 0) { const char* e = getenv("UMV_GEMM_SKINNY_MAX"); skinny_max = e ? atoi(e) : 64; }
+    if (a.M <= 64 && (a.M <= skinny_max || TH != 16)) {
         const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
         if (a.M <= 16) {
             if (a.norm_w && a.M <= 8) return two ? launch_skinny<1, 2, 4, true, 8>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, 8>(a, KT, NTT, s);
