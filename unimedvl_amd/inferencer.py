@@ -228,9 +228,167 @@ class InterleaveInferencer:
             cfg_text_precontext = self.update_context_image(processed, cfg_text_precontext, vae=True, vit=False)
         return output_list
 
+    # ------------------------------------------------------------------ batch extension (additive)
+    # The reference runs one sample per call (contexts are lists of length 1).  Samples are independent segments of
+    # the packed NaViT sequence, so B samples with the same item structure (e.g. [image, question]) share every
+    # forward: one ViT / prefill / decode / flow pass over B segments, per-sample EOS.
+    def _batch_context(self, n):
+        return {"kv_lens": [0] * n, "ropes": [0] * n,
+                "past_key_values": NaiveCache(self.model.config.llm_config.num_hidden_layers)}
+
+    def _update_batch_text(self, texts, ctx):
+        gi, kv_lens, ropes = self.model.prepare_prompts(curr_kvlens=ctx["kv_lens"], curr_rope=ctx["ropes"], prompts=list(texts),
+                                                        tokenizer=self.tokenizer, new_token_ids=self.new_token_ids)
+        pkv = self.model.forward_cache_update_text(ctx["past_key_values"], **gi)
+        ctx["kv_lens"], ctx["ropes"], ctx["past_key_values"] = kv_lens, ropes, pkv
+        return ctx
+
+    def _update_batch_image(self, images, ctx, vae=True, vit=True):
+        pkv, kv_lens, ropes = ctx["past_key_values"], ctx["kv_lens"], ctx["ropes"]
+        if vae:
+            gi, kv_lens, ropes = self.model.prepare_vae_images(curr_kvlens=kv_lens, curr_rope=ropes, images=list(images),
+                                                               transforms=self.vae_transform, new_token_ids=self.new_token_ids)
+            pkv = self.model.forward_cache_update_vae(self.vae_model, pkv, **gi)
+        if vit:
+            gi, kv_lens, ropes = self.model.prepare_vit_images(curr_kvlens=kv_lens, curr_rope=ropes, images=list(images),
+                                                               transforms=self.vit_transform, new_token_ids=self.new_token_ids)
+            pkv = self.model.forward_cache_update_vit(pkv, **gi)
+        ctx["kv_lens"], ctx["ropes"], ctx["past_key_values"] = kv_lens, ropes, pkv
+        return ctx
+
+    @torch.no_grad()
+    def gen_text_batch(self, ctx, max_length: int = 500, do_sample: bool = True, temperature: float = 1.0) -> List[str]:
+        """gen_text for every sample of a batched context; each answer ends at that sample's own EOS."""
+        ctx = deepcopy(ctx)
+        eos = self.new_token_ids["eos_token_id"]
+        gi = self.model.prepare_start_tokens(ctx["kv_lens"], ctx["ropes"], self.new_token_ids)
+        ids = self.model.generate_text(past_key_values=ctx["past_key_values"], max_length=max_length, do_sample=do_sample,
+                                       temperature=temperature, end_token_id=eos, per_sample_eos=True, **gi).cpu()
+        out = []
+        for b in range(ids.shape[1]):
+            col = ids[:, b]
+            hit = (col[1:] == eos).nonzero()
+            n = int(hit[0]) + 1 if hit.numel() else col.numel()   # rows fed before this sample's EOS (row 0 = start token)
+            text = self.tokenizer.decode(col[:n])
+            out.append(text.split("<|im_end|>")[0].split("<|im_start|>")[1])
+        return out
+
+    @torch.no_grad()
+    def gen_image_batch(self, image_shapes, ctx, cfg_text_precontext, cfg_img_precontext, cfg_text_scale=4.0, cfg_img_scale=1.5,
+                        cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0, cfg_renorm_type="global", num_timesteps=50,
+                        timestep_shift=3.0) -> List[Image.Image]:
+        m = self.model
+        n = len(ctx["kv_lens"])
+        shapes = [tuple(image_shapes)] * n if isinstance(image_shapes[0], int) else [tuple(s) for s in image_shapes]
+        gi = m.prepare_vae_latent(curr_kvlens=ctx["kv_lens"], curr_rope=ctx["ropes"], image_sizes=shapes,
+                                  new_token_ids=self.new_token_ids)
+        gt = m.prepare_vae_latent_cfg(curr_kvlens=cfg_text_precontext["kv_lens"], curr_rope=cfg_text_precontext["ropes"],
+                                      image_sizes=shapes)
+        gim = m.prepare_vae_latent_cfg(curr_kvlens=cfg_img_precontext["kv_lens"], curr_rope=cfg_img_precontext["ropes"],
+                                       image_sizes=shapes)
+        latents = m.generate_image(
+            past_key_values=ctx["past_key_values"], cfg_text_past_key_values=cfg_text_precontext["past_key_values"],
+            cfg_img_past_key_values=cfg_img_precontext["past_key_values"], num_timesteps=num_timesteps,
+            cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval,
+            cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type, timestep_shift=timestep_shift, **gi,
+            cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+            cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+            cfg_text_key_values_lens=gt["cfg_key_values_lens"],
+            cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+            cfg_img_packed_position_ids=gim["cfg_packed_position_ids"],
+            cfg_img_packed_query_indexes=gim["cfg_packed_query_indexes"],
+            cfg_img_key_values_lens=gim["cfg_key_values_lens"],
+            cfg_img_packed_key_value_indexes=gim["cfg_packed_key_value_indexes"])
+        return [self.decode_image(lat, shp) for lat, shp in zip(latents, shapes)]
+
+    @torch.no_grad()
+    def batch_interleave_inference(self, input_lists: List[List[Union[str, Image.Image]]], think=False,
+                                   understanding_output=False, max_think_token_n=1000, do_sample=False, text_temperature=0.3,
+                                   cfg_text_scale=3.0, cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), timestep_shift=3.0,
+                                   num_timesteps=50, cfg_renorm_min=0.0, cfg_renorm_type="global", image_shapes=(1024, 1024)
+                                   ) -> List[List[Union[str, Image.Image]]]:
+        """interleave_inference (inferencer.py:552-638) over B samples at once.  Every sample must have the same
+        sequence of item types; lengths (prompt tokens, image sizes) may differ.  Returns one output list per sample."""
+        n = len(input_lists)
+        if n == 0:
+            return []
+        kinds = [tuple("s" if isinstance(t, str) else "i" if isinstance(t, Image.Image) else "?" for t in items) for items in input_lists]
+        if any("?" in k for k in kinds):
+            raise ValueError("Unsupported input type in a batched input list")
+        if len(set(kinds)) != 1:
+            raise ValueError("batched samples must share one item structure (e.g. every sample = [image, text])")
+        need_cfg = not understanding_output
+        ctx = self._batch_context(n)
+        cfg_text_ctx, cfg_img_ctx = deepcopy(ctx), deepcopy(ctx)
+        if think:
+            sp = VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT
+            ctx = self._update_batch_text([sp] * n, ctx)
+            if need_cfg:
+                cfg_img_ctx = self._update_batch_text([sp] * n, cfg_img_ctx)
+        for j, kind in enumerate(kinds[0]):
+            column = [items[j] for items in input_lists]
+            if kind == "s":
+                if need_cfg:
+                    cfg_text_ctx = deepcopy(ctx)
+                ctx = self._update_batch_text(column, ctx)
+                if need_cfg:
+                    cfg_img_ctx = self._update_batch_text(column, cfg_img_ctx)
+            else:
+                column = [self.vae_transform.resize_transform(pil_img2rgb(im)) for im in column]
+                ctx = self._update_batch_image(column, ctx, vae=not understanding_output)
+                if need_cfg:
+                    cfg_text_ctx = deepcopy(ctx)
+        outputs = [[] for _ in range(n)]
+        if understanding_output:
+            for o, t in zip(outputs, self.gen_text_batch(ctx, do_sample=do_sample, temperature=text_temperature,
+                                                         max_length=max_think_token_n)):
+                o.append(t)
+            return outputs
+        if think:
+            thoughts = self.gen_text_batch(ctx, do_sample=do_sample, temperature=text_temperature, max_length=max_think_token_n)
+            ctx = self._update_batch_text(thoughts, ctx)
+            for o, t in zip(outputs, thoughts):
+                o.append(t)
+        images = self.gen_image_batch(image_shapes, ctx, cfg_text_precontext=cfg_text_ctx, cfg_img_precontext=cfg_img_ctx,
+                                      cfg_text_scale=cfg_text_scale, cfg_img_scale=cfg_img_scale, cfg_interval=cfg_interval,
+                                      timestep_shift=timestep_shift, num_timesteps=num_timesteps, cfg_renorm_min=cfg_renorm_min,
+                                      cfg_renorm_type=cfg_renorm_type)
+        for o, im in zip(outputs, images):
+            o.append(im)
+        return outputs
+
+    @staticmethod
+    def _collect(output_list):
+        output_dict = {"image": None, "text": None}
+        for item in output_list:
+            if isinstance(item, Image.Image):
+                if output_dict["image"] is None:
+                    output_dict["image"] = []
+                output_dict["image"].append(item)
+            elif isinstance(item, str):
+                output_dict["text"] = item
+        if isinstance(output_dict["image"], list) and len(output_dict["image"]) == 1:
+            output_dict["image"] = output_dict["image"][0]
+        return output_dict
+
     def __call__(self, image: Optional[Union[Image.Image, List[Image.Image]]] = None, text: Optional[str] = None,
                  inference_ver=0, **kargs) -> Dict[str, Any]:
-        """inferencer.py:640-680: images first, then the text; {'image': PIL|list|None, 'text': str|None}."""
+        """inferencer.py:640-680: images first, then the text; {'image': PIL|list|None, 'text': str|None}.
+        Batch extension: `text` as a LIST of prompts (and `image` as a list of the same length whose entries are a PIL
+        image, a list of PIL images, or None for all) runs the samples together and returns a list of such dicts."""
+        if isinstance(text, (list, tuple)):
+            if inference_ver != 0:
+                raise ValueError("the batched call supports inference_ver=0 only")
+            n = len(text)
+            if image is None:
+                image = [None] * n
+            if not isinstance(image, (list, tuple)) or len(image) != n:
+                raise ValueError("batched call: `image` must be None or a list with one entry per prompt")
+            input_lists = []
+            for im, tx in zip(image, text):
+                items = [] if im is None else (list(im) if isinstance(im, (list, tuple)) else [im])
+                input_lists.append(items + [tx])
+            return [self._collect(o) for o in self.batch_interleave_inference(input_lists, **kargs)]
         output_dict = {"image": None, "text": None}
         if image is None and text is None:
             return output_dict
