@@ -287,10 +287,19 @@ def main():
         torch.manual_seed(12)
         edit = inf(image=pil, text="9 10", image_shapes=(64, 48), num_timesteps=3, cfg_text_scale=4.0, cfg_img_scale=2.0,
                    cfg_interval=(0.0, 1.0), timestep_shift=3.0, cfg_renorm_type="text_channel")
+        # VQA + reconstruction variants (inferencer.py:282-549): ver1 through __call__, ver0_1 / ver0 called directly
+        rec = dict(reconstruct_image=True, max_think_token_n=6, num_timesteps=3, cfg_text_scale=4.0, cfg_img_scale=2.0,
+                   cfg_interval=(0.0, 1.0), timestep_shift=3.0, cfg_renorm_type="global")
+        torch.manual_seed(13)
+        ver1 = inf(image=pil, text="5 6 7 8", inference_ver=1, **rec)
+        torch.manual_seed(14)
+        ver01 = inf.interleave_inference_for_vqa_reconstruction_ver0_1([pil, "5 6 7 8"], **rec)
     np.savez(os.path.join(OUT, "inferencer.npz"), **pack(dict(
         weights_sha=wdig, pil_image=torch.from_numpy(np.asarray(pil).copy()), und_text=und["text"],
         t2i_image=torch.from_numpy(np.asarray(t2i["image"]).copy()),
-        edit_image=torch.from_numpy(np.asarray(edit["image"]).copy()))))
+        edit_image=torch.from_numpy(np.asarray(edit["image"]).copy()),
+        ver1_text=ver1["text"], ver1_image=torch.from_numpy(np.asarray(ver1["image"]).copy()),
+        ver01_text=ver01[0], ver01_image=torch.from_numpy(np.asarray(ver01[1]).copy()))))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(" ", f, os.path.getsize(os.path.join(OUT, f)))

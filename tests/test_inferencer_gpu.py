@@ -66,6 +66,33 @@ def test_interleave_inferencer_call(stack):
         inf.interleave_inference([3.14])
 
 
+def test_vqa_reconstruction_variants(stack):
+    """inference_ver=1 through __call__ and the older ver0_1 / ver0 methods (inferencer.py:282-549) against the
+    reference's own runs.  ver0_1 / ver0 hard-code both guidance scales to 7.0 (49x amplification of rounding noise
+    per guided step), so their pixel tolerance is wider; texts must match exactly."""
+    from unimedvl_amd.inferencer import InterleaveInferencer
+    from unimedvl_amd.transforms import ImageTransform
+    model, vae, tok = stack
+    g = load_golden("inferencer")
+    pil = Image.fromarray(g["pil_image"].numpy())
+    inf = InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16), ImageTransform(56, 28, 14), NEW_TOKEN_IDS)
+    rec = dict(reconstruct_image=True, max_think_token_n=6, num_timesteps=3, cfg_text_scale=4.0, cfg_img_scale=2.0,
+               cfg_interval=(0.0, 1.0), timestep_shift=3.0, cfg_renorm_type="global")
+    torch.manual_seed(13)
+    v1 = inf(image=pil, text="5 6 7 8", inference_ver=1, **rec)
+    assert v1["text"] == g["ver1_text"]
+    pixel_close(v1["image"], g["ver1_image"], "ver1 reconstruction", min_frac=0.90, max_mean=3.0)
+    torch.manual_seed(14)
+    v01 = inf.interleave_inference_for_vqa_reconstruction_ver0_1([pil, "5 6 7 8"], **rec)
+    assert len(v01) == 2 and v01[0] == g["ver01_text"]
+    pixel_close(v01[1], g["ver01_image"], "ver0_1 reconstruction", min_frac=0.80, max_mean=6.0)
+    torch.manual_seed(14)
+    v0 = inf.interleave_inference_for_vqa_reconstruction_ver0([pil, pil, "5 6 7 8"], **rec)
+    assert len(v0) == 2 and isinstance(v0[0], str) and v0[1].size == v01[1].size     # first image only
+    torch.manual_seed(14)   # the VQA context holds a SAMPLED VAE latent of the image: the answer depends on the seed
+    assert inf.interleave_inference_for_vqa_reconstruction_ver0([pil, "5 6 7 8"], max_think_token_n=6) == [g["ver01_text"]]
+
+
 def test_batched_call_matches_single_calls(stack):
     """Batch extension: lists in, list of dicts out, per-sample EOS.  Samples are independent
     segments, so a batched greedy VQA run must give each sample the answer its own single-sample call gives

@@ -228,6 +228,62 @@ class InterleaveInferencer:
             cfg_text_precontext = self.update_context_image(processed, cfg_text_precontext, vae=True, vit=False)
         return output_list
 
+    def _vqa_then_rebuild(self, input_lists, reconstruct_image, first_only, do_sample, text_temperature, max_think_token_n,
+                          cfg_interval, timestep_shift, num_timesteps, cfg_renorm_min, cfg_renorm_type):
+        """Shared body of the two older VQA+reconstruction variants (inferencer.py:366-549): answer the question with
+        the image(s) in both ViT and VAE form, then regenerate the image(s) from a FRESH context = [image, answer], with
+        cfg_text context = [image] and cfg_img context = [answer], both guidance scales fixed at 7.0 by the reference."""
+        ctx = self.init_gen_context()
+        for item in input_lists:
+            if isinstance(item, str):
+                ctx = self.update_context_text(item, ctx)
+            elif isinstance(item, Image.Image):
+                ctx = self.update_context_image(self.vae_transform.resize_transform(pil_img2rgb(item)), ctx, vae=True, vit=True)
+            else:
+                raise ValueError(f"Unsupported input type: {type(item)}")
+        answer = self.gen_text(ctx, do_sample=do_sample, temperature=text_temperature, max_length=max_think_token_n)
+        outputs = [answer]
+        pictures = [it for it in input_lists if isinstance(it, Image.Image)]
+        if not reconstruct_image or not answer or not answer.strip() or not pictures:
+            return outputs
+        for picture in (pictures[:1] if first_only else pictures):
+            w, h = picture.size
+            target = self._calculate_target_size_with_aspect_ratio(w, h)
+            resized = self.vae_transform.resize_transform(pil_img2rgb(picture))
+            image_only = self.update_context_image(resized, self.init_gen_context(), vae=True, vit=True)
+            image_and_answer = self.update_context_text(answer, deepcopy(image_only))
+            answer_only = self.update_context_text(answer, self.init_gen_context())
+            outputs.append(self.gen_image(
+                target, image_and_answer, cfg_text_precontext=image_only, cfg_img_precontext=answer_only, cfg_text_scale=7.0,
+                cfg_img_scale=7.0, cfg_interval=cfg_interval, timestep_shift=timestep_shift, num_timesteps=num_timesteps,
+                cfg_renorm_min=cfg_renorm_min, cfg_renorm_type=cfg_renorm_type))
+        return outputs
+
+    @torch.no_grad()
+    def interleave_inference_for_vqa_reconstruction_ver0_1(
+            self, input_lists: List[Union[str, Image.Image]], reconstruct_image: bool = False, think: bool = False,
+            understanding_output: bool = True, max_think_token_n: int = 1000, do_sample: bool = False,
+            text_temperature: float = 0.3, cfg_text_scale: float = 3.0, cfg_img_scale: float = 1.5,
+            cfg_interval: list = (0.4, 1.0), timestep_shift: float = 3.0, num_timesteps: int = 50,
+            cfg_renorm_min: float = 0.0, cfg_renorm_type: str = "global", image_shapes: tuple = (1024, 1024)
+    ) -> List[Union[str, Image.Image]]:
+        """inferencer.py:366-463: VQA, then one reconstruction per input image.  (cfg_*_scale / think / image_shapes are
+        accepted and ignored, as in the reference.)"""
+        return self._vqa_then_rebuild(input_lists, reconstruct_image, False, do_sample, text_temperature, max_think_token_n,
+                                      cfg_interval, timestep_shift, num_timesteps, cfg_renorm_min, cfg_renorm_type)
+
+    @torch.no_grad()
+    def interleave_inference_for_vqa_reconstruction_ver0(
+            self, input_lists: List[Union[str, Image.Image]], reconstruct_image: bool = False, think: bool = False,
+            understanding_output: bool = True, max_think_token_n: int = 1000, do_sample: bool = False,
+            text_temperature: float = 0.3, cfg_text_scale: float = 3.0, cfg_img_scale: float = 1.5,
+            cfg_interval: list = (0.4, 1.0), timestep_shift: float = 3.0, num_timesteps: int = 50,
+            cfg_renorm_min: float = 0.0, cfg_renorm_type: str = "global", image_shapes: tuple = (1024, 1024)
+    ) -> List[Union[str, Image.Image]]:
+        """inferencer.py:466-549: VQA, then a reconstruction of the FIRST input image only."""
+        return self._vqa_then_rebuild(input_lists, reconstruct_image, True, do_sample, text_temperature, max_think_token_n,
+                                      cfg_interval, timestep_shift, num_timesteps, cfg_renorm_min, cfg_renorm_type)
+
     # ------------------------------------------------------------------ batch extension (additive; SURVEY.md section 8b B1)
     # The reference runs one sample per call (contexts are lists of length 1).  Samples are independent segments of
     # the packed NaViT sequence, so B samples with the same item structure (e.g. [image, question]) share every
