@@ -49,9 +49,11 @@ def process_conversation(images, conversation):
 
 
 def load_tokenizer(model_path):
-    """Qwen2 byte-level BPE from the checkpoint's vocab.json / merges.txt (HF tokenizers; host side)."""
-    from transformers import AutoTokenizer
-    return AutoTokenizer.from_pretrained(model_path)
+    """Qwen2 byte-level BPE from the checkpoint's vocab.json / merges.txt / tokenizer_config.json
+    (Qwen2Tokenizer.from_pretrained(model_path), interactive_vqa_inferencer.py:236): the in-tree implementation,
+    id-for-id equal to the reference's class (tests/test_tokenizer_cpu.py); no transformers import at run time."""
+    from .tokenizer import Qwen2Tokenizer
+    return Qwen2Tokenizer.from_pretrained(model_path)
 
 
 class VQAInferencer:
