@@ -80,6 +80,12 @@ typedef struct {
     int tile_rows;            /* rows per n-tile of `wp`: 0 or 16 = umv_pack_weight_bf16 image; 1..15 = an image made by
                                  umv_repack_weight_rows_bf16 (decode only, M <= 64) */
     const float* w_scale;     /* umv_gemm_fp8w only: per-channel scales written by umv_quantize_pack_weight_fp8 */
+    int k_splits;             /* > 1 (umv_gemm_bf16, M <= 64, 16-row image, no SwiGLU / norm_w): split-K decode mode. K is cut
+                                 into k_splits ranges; `out` is then an fp32 buffer [k_splits][rows][ldo] (split s at
+                                 out + s*split_stride) of RAW partial sums - no bias, activation or residual: the consumer
+                                 (umv_qkv_post partials input, umv_residual_rmsnorm_bf16) adds the splits in order 0..S-1 and
+                                 finishes the row with the reference's roundings */
+    int64_t split_stride;     /* elements between consecutive splits of `out` */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 
@@ -126,6 +132,11 @@ int umv_gemm_decode(const umv_gemm_args* a, const umv_decode_layout* L, int fp8,
  * qwen2_navit.py:863-865,893-894,1166-1168).  row_idx optional gather/scatter. */
 int umv_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* w_gen, const int32_t* expert,
                      uint16_t* out, int T, int H, float eps, umv_stream_t stream);
+/* Consumer of a split-K decode GEMM (o_proj / down_proj, qwen2_navit.py:617-620, modeling_qwen2.py:235) fused with the
+ * residual add (qwen2_navit.py:873-874,897-898) and the following Qwen2RMSNorm:
+ *   seq[t,:] = bf16(bf16(sum_s partials[s*split_stride + t*ldp + :]) + seq[t,:])  (in place);  out = w * bf16(seq * rstd) */
+int umv_residual_rmsnorm_bf16(const float* partials, int n_splits, int64_t split_stride, int64_t ldp, uint16_t* seq,
+                              const uint16_t* w, uint16_t* out, int T, int H, float eps, umv_stream_t stream);
 /* nn.LayerNorm with affine, bf16 in/out, fp32 statistics (siglip_navit.py:283,296,370) */
 int umv_layernorm_bf16(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int T, int H,
                        float eps, umv_stream_t stream);
@@ -174,6 +185,12 @@ typedef struct {
     int T, nq, nkv, hd;
     float eps;
     int fp32_chain;
+    /* optional: take the fused QKV row from a split-K GEMM (umv_gemm_args.k_splits) instead of `qkv`:
+     * x = bf16(sum_s qkv_partials[s*split_stride + t*(nq+2nkv)*hd + col] + qkv_bias[col]), splits in order 0..S-1 */
+    const float* qkv_partials;
+    int n_splits;
+    int64_t split_stride;
+    const uint16_t* qkv_bias;
 } umv_qkv_post_args;
 int umv_qkv_post(const umv_qkv_post_args* a, umv_stream_t stream);
 

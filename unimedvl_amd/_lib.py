@@ -20,6 +20,7 @@ class GemmArgs(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
         ("row_idx", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
         ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("tile_rows", C.c_int), ("w_scale", C.c_void_p),
+        ("k_splits", C.c_int), ("split_stride", C.c_int64),
     ]
 
 
@@ -37,6 +38,7 @@ class QkvPostArgs(C.Structure):
         ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
         ("T", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("eps", C.c_float),
         ("fp32_chain", C.c_int),
+        ("qkv_partials", C.c_void_p), ("n_splits", C.c_int), ("split_stride", C.c_int64), ("qkv_bias", C.c_void_p),
     ]
 
 
@@ -79,6 +81,8 @@ _SIGS = {
     "umv_repack_weight_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(DecodeLayout), C.c_void_p]),
     "umv_gemm_decode": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(DecodeLayout), C.c_int, C.c_void_p]),
+    "umv_residual_rmsnorm_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_float, C.c_void_p]),
     "umv_rmsnorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_float, C.c_void_p]),
     "umv_layernorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,

@@ -130,6 +130,76 @@ extern "C" int umv_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, const uint
     return UMV_OK;
 }
 
+// Consumer of a split-K decode GEMM (umv_gemm_args.k_splits): finishes o_proj / down_proj and runs the next RMSNorm in
+// one launch.   seq[t,:] = bf16( bf16(sum_s P[s][t,:]) + seq[t,:] )   (the GEMM output rounding, then the residual add:
+// qwen2_navit.py:873-874,897-898), splits added in order 0..S-1;   out[t,:] = w * bf16(seq * rstd)   (modeling_qwen2.py:89-94)
+template <int MAXV>
+__global__ __launch_bounds__(256) void residual_rmsnorm_kernel(const float* __restrict__ P, int S, int64_t sstride, int64_t ldp,
+                                                               bf16_t* __restrict__ seq, const bf16_t* __restrict__ w,
+                                                               bf16_t* __restrict__ out, int H, float eps) {
+    __shared__ float part[4];
+    const int row = blockIdx.x;
+    const int nv = H / 8;
+    bf16x8 v[MAXV], ww[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + threadIdx.x;
+        v[i] = zero_frag();
+        ww[i] = zero_frag();
+        if (c < nv) {
+            const bf16x8 res = ldg_frag(seq + (int64_t)row * H + c * 8);
+            ww[i] = ldg_frag(w + c * 8);
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* p = P + (int64_t)row * ldp + c * 8;
+            for (int s = 0; s < S; ++s) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + s * sstride);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + s * sstride + 4);
+                acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+                acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = rbf(rbf(acc[j]) + bf2f((bf16_t)res[j]));
+                v[i][j] = (short)f2bf(f);
+                ss += f * f;
+            }
+            *reinterpret_cast<bf16x8*>(seq + (int64_t)row * H + c * 8) = v[i];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    const float rstd = rsqrt_ieee(tot / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 256 + threadIdx.x;
+        if (c < nv) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bf2f((bf16_t)ww[i][j]) * rbf(bf2f((bf16_t)v[i][j]) * rstd));
+            *reinterpret_cast<bf16x8*>(out + (int64_t)row * H + c * 8) = o;
+        }
+    }
+}
+
+extern "C" int umv_residual_rmsnorm_bf16(const float* partials, int n_splits, int64_t split_stride, int64_t ldp, uint16_t* seq,
+                                         const uint16_t* w, uint16_t* out, int T, int H, float eps, umv_stream_t stream) {
+    UMV_CHECK(partials && seq && w && out, UMV_ERR_ARG, "residual_rmsnorm: null pointer");
+    UMV_CHECK(n_splits >= 1 && n_splits <= 64 && split_stride >= 0 && ldp >= H, UMV_ERR_ARG, "residual_rmsnorm: bad split layout");
+    UMV_CHECK(H % 8 == 0 && H <= 256 * 8 * 4 && (ldp % 4) == 0 && (split_stride % 4) == 0, UMV_ERR_ARG,
+              "residual_rmsnorm: H=%d (multiple of 8, <= 8192) / ldp / split_stride (multiples of 4) unsupported", H);
+    if (T == 0) return UMV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 256 * 8 * 2)
+        hipLaunchKernelGGL((residual_rmsnorm_kernel<2>), dim3(T), dim3(256), 0, s, partials, n_splits, split_stride, ldp, seq, w, out, H, eps);
+    else
+        hipLaunchKernelGGL((residual_rmsnorm_kernel<4>), dim3(T), dim3(256), 0, s, partials, n_splits, split_stride, ldp, seq, w, out, H, eps);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
 // ----------------------------------------------------------------------------- LayerNorm
 // F.layer_norm on bf16 (siglip_navit.py:283,296,370): fp32 statistics, one rounding to bf16.
 template <int MAXV>
@@ -416,7 +486,19 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
     const bool is_q = h < a.nq, is_k = !is_q && h < a.nq + a.nkv;
     const bool act = lane < HALF;  // HD=128: all 64 lanes; HD=72: 36 lanes
     float x1 = 0.f, x2 = 0.f;
-    if (act) { x1 = bf2f(src[lane]); x2 = bf2f(src[lane + HALF]); }
+    if (act) {
+        if (a.qkv_partials) {   // split-K QKV GEMM: x = bf16(sum_s P[s] + bias), the rounding of the GEMM epilogue it replaces
+            const int64_t col = (int64_t)h * HD + lane;
+            const float* p = a.qkv_partials + (int64_t)t * nheads * HD + col;
+            for (int s = 0; s < a.n_splits; ++s) { x1 += p[s * a.split_stride]; x2 += p[s * a.split_stride + HALF]; }
+            if (a.qkv_bias) { x1 += bf2f(a.qkv_bias[col]); x2 += bf2f(a.qkv_bias[col + HALF]); }
+            x1 = rbf(x1);
+            x2 = rbf(x2);
+        } else {
+            x1 = bf2f(src[lane]);
+            x2 = bf2f(src[lane + HALF]);
+        }
+    }
     if (!is_q && !is_k) {  // V head: transposed store V^T[seg][kvh][d][slot]
         const int kvh = h - a.nq - a.nkv;
         bf16_t* dst = a.vt_slab + seg * a.v_seg_stride + kvh * a.v_head_stride + slot;
@@ -492,7 +574,9 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(umv_qkv_post_args a) {
 extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap, UMV_ERR_ARG, "qkv_post: null args");
     const umv_qkv_post_args& a = *ap;
-    UMV_CHECK(a.qkv && a.q_out && a.k_slab && a.vt_slab && a.tok_seg && a.tok_slot, UMV_ERR_ARG, "qkv_post: null pointer");
+    UMV_CHECK((a.qkv || a.qkv_partials) && a.q_out && a.k_slab && a.vt_slab && a.tok_seg && a.tok_slot, UMV_ERR_ARG, "qkv_post: null pointer");
+    UMV_CHECK(!a.qkv_partials || (a.q_norm_w && a.n_splits >= 1 && a.n_splits <= 64), UMV_ERR_ARG,
+              "qkv_post: fp32 partial input needs the norm + RoPE path and 1 <= n_splits <= 64");
     UMV_CHECK(!a.q_norm_w || (a.k_norm_w && a.cos_tab && a.sin_tab && a.tok_pos), UMV_ERR_ARG, "qkv_post: norm without rope tables");
     UMV_CHECK(!a.expert || (a.q_norm_w_gen && a.k_norm_w_gen), UMV_ERR_ARG, "qkv_post: expert routing without gen norms");
     if (a.T == 0) return UMV_OK;

@@ -153,9 +153,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int kt_per = (KT + SK_WAVES - 1) / SK_WAVES;
-    const int kt_begin = wave * kt_per;
-    const int kt_end = min(KT, kt_begin + kt_per);
+    // split-K (a.k_splits > 1): blockIdx.y owns the k-tiles [ks0, ks1) and stores raw fp32 partial sums
+    const int nsplit = a.k_splits > 1 ? a.k_splits : 1;
+    const int kts = (KT + nsplit - 1) / nsplit;
+    const int ks0 = (int)blockIdx.y * kts, ks1 = min(KT, ks0 + kts);
+    const int kt_per = (max(0, ks1 - ks0) + SK_WAVES - 1) / SK_WAVES;
+    const int kt_begin = ks0 + wave * kt_per;
+    const int kt_end = min(ks1, kt_begin + kt_per);
     const int nk = max(0, kt_end - kt_begin);
     const int nchunks = (nk + U - 1) / U;
     // TH = rows per n-tile of the packed image (16 standard; < 16 for the exact-partition decode copies,
@@ -311,6 +315,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
         }
     __syncthreads();
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    if (nsplit > 1) {   // partial sums: fp32, no bias / activation / residual (the consumer kernel finishes the row)
+        e.out = reinterpret_cast<float*>(a.out) + (int64_t)blockIdx.y * a.split_stride;
+        e.flags = UMV_EPI_OUT_F32;
+    }
     if (a.epilogue & UMV_EPI_SWIGLU) {
         // tiles come in (gate, up) pairs; NT is even
         for (int idx = tid; idx < (NT / 2) * MB * 64; idx += SK_WAVES * 64) {
@@ -496,9 +504,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int kt_per = (KT8 + SK_WAVES - 1) / SK_WAVES;
-    const int kt_begin = wave * kt_per;
-    const int kt_end = min(KT8, kt_begin + kt_per);
+    const int nsplit = a.k_splits > 1 ? a.k_splits : 1;   // split-K as in gemm_skinny_kernel (over 64-wide super-tiles)
+    const int kts = (KT8 + nsplit - 1) / nsplit;
+    const int ks0 = (int)blockIdx.y * kts, ks1 = min(KT8, ks0 + kts);
+    const int kt_per = (max(0, ks1 - ks0) + SK_WAVES - 1) / SK_WAVES;
+    const int kt_begin = ks0 + wave * kt_per;
+    const int kt_end = min(ks1, kt_begin + kt_per);
     const int nk = max(0, kt_end - kt_begin);
     const int nchunks = (nk + U - 1) / U;
     const uint8_t* wbase[NT];
@@ -563,6 +574,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
         for (int mb = 0; mb < MB; ++mb) reinterpret_cast<f32x4*>(red)[(wave * E4 + t * MB + mb) * 64 + lane] = acc[t][mb];
     __syncthreads();
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    if (nsplit > 1) {
+        e.out = reinterpret_cast<float*>(a.out) + (int64_t)blockIdx.y * a.split_stride;
+        e.flags = UMV_EPI_OUT_F32;
+    }
     if (a.epilogue & UMV_EPI_SWIGLU) {
         for (int idx = tid; idx < (NT / 2) * MB * 64; idx += SK_WAVES * 64) {
             int l = idx & 63;
@@ -605,7 +620,8 @@ template <int MB, int NT, int U>
 static int launch_skinny8(const umv_gemm_args& a, int KT8, int NTT, hipStream_t s) {
     int blocks = (NTT + NT - 1) / NT;
     size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny8_kernel<MB, NT, U>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT8, NTT);
+    hipLaunchKernelGGL((gemm_skinny8_kernel<MB, NT, U>), dim3(blocks, a.k_splits > 1 ? a.k_splits : 1), dim3(SK_WAVES * 64), lds, s, a,
+                       KT8, NTT);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -623,13 +639,23 @@ extern "C" int umv_gemm_fp8w(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(!(a.epilogue & UMV_EPI_RESIDUAL) || a.residual, UMV_ERR_ARG, "gemm_fp8w: RESIDUAL without residual pointer");
     UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm_fp8w: SWIGLU needs N %% 32 == 0");
     UMV_CHECK(!a.norm_w && (a.tile_rows == 0 || a.tile_rows == 16), UMV_ERR_UNSUPPORTED, "gemm_fp8w: no fused norm / th-row tiles");
+    UMV_CHECK(a.k_splits <= 1 || (!(a.epilogue & UMV_EPI_SWIGLU) && a.split_stride > 0 && a.k_splits <= 64), UMV_ERR_UNSUPPORTED,
+              "gemm_fp8w: split-K (k_splits=%d) needs no SwiGLU, split_stride > 0, k_splits <= 64", a.k_splits);
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT8 = (a.K + 63) / 64, NTT = (a.N + 15) / 16;
+    if (a.k_splits > 1) {   // split-K decode mode: see umv_gemm_bf16
+        if (a.M <= 16) return launch_skinny8<1, 4, 1>(a, KT8, NTT, s);
+        if (a.M <= 32) return launch_skinny8<2, 4, 1>(a, KT8, NTT, s);
+        return launch_skinny8<4, 4, 1>(a, KT8, NTT, s);
+    }
     const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
     // (NT, U) from a sweep on MI355X at M = 8 (tools/skinny_bench.py, FP8=1): gate/up 25.5 us with <2,2> (110 VGPRs, two
     // workgroups per CU) vs 33.9 <2,4>, 27.9 <4,1>; down_proj 18.2 us with <1,8> vs 23.7 for NT = 2 (only 112 workgroups)
     if (a.M <= 16) return two ? launch_skinny8<1, 2, 2>(a, KT8, NTT, s) : launch_skinny8<1, 1, 8>(a, KT8, NTT, s);
+    static int nt4 = -1;   // as in umv_gemm_bf16: 4 n-tiles per workgroup on the wide-N GEMMs at M > 16 (UMV_GEMM_SKINNY_NT=2 reverts)
+    if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : 1; }
+    if (two && nt4) return a.M <= 32 ? launch_skinny8<2, 4, 1>(a, KT8, NTT, s) : launch_skinny8<4, 4, 1>(a, KT8, NTT, s);
     if (a.M <= 32) return two ? launch_skinny8<2, 2, 2>(a, KT8, NTT, s) : launch_skinny8<2, 1, 4>(a, KT8, NTT, s);
     return two ? launch_skinny8<4, 2, 1>(a, KT8, NTT, s) : launch_skinny8<4, 1, 2>(a, KT8, NTT, s);
 }
@@ -733,14 +759,26 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         // Register double buffering (KTS == 1): the fragments of tile t+1 are read from LDS while the MFMAs of
         // tile t run out of registers, so the matrix pipe does not wait for ds_read latency after each barrier.
         static_assert(PRIO != 2 || (KTS == 1 && NBUF >= 3), "fragment double buffering needs KTS == 1 and >= 3 LDS buffers");
+        // The LDS reads are inline asm with a MANUAL s_waitcnt: left to the compiler, the loop-carried fragments get a
+        // conservative `s_waitcnt lgkmcnt(0)` right after the next tile's ds_reads are issued (seen in the ISA), which
+        // serialises exactly what this variant is meant to overlap.
         bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
         auto ldfrag = [&](int buf, bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
-            const char* wb = smem + buf * BUF;
-            const char* xb = wb + WTILES * 1024;
+            const uint32_t wa = lds0 + buf * BUF + wn * TN * 1024 + lane * 16;
+            const uint32_t xa = lds0 + buf * BUF + WTILES * 1024 + wm * TM * 1024 + lane * 16;
 #pragma unroll
-            for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + (wn * TN + t) * 1024 + lane * 16);
+            for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[t]) : "v"(wa + t * 1024));
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + (wm * TM + j) * 1024 + lane * 16);
+            for (int j = 0; j < TM; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(xa + j * 1024));
+        };
+        // the fragments issued one step earlier have landed; the "+v" ties order every later use after the wait
+        auto wait_frags = [&](bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(wf[t]));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
         };
         auto wait_tiles = [&](int allowed) {   // tiles (of TPW DMA ops each) that may stay in flight
             if (allowed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
@@ -755,6 +793,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             if (more) wait_tiles(min(NBUF - 3, nsteps - 2 - step));      // tile step+1 landed (mine)
             __builtin_amdgcn_s_barrier();                                // ... everyone's; and tile step-1's buffer is free
             if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
+            wait_frags(wc, xc);
             if (more) ldfrag((step + 1) % NBUF, wnx, xnx);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
@@ -845,7 +884,8 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
     int blocks = (NTT + NT - 1) / NT;
     size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
     if (NORM) lds += SK_WAVES * 16 * sizeof(float) + (size_t)KT * 4 * NORM * 16;
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, a, KT, NTT);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM>), dim3(blocks, a.k_splits > 1 ? a.k_splits : 1), dim3(SK_WAVES * 64), lds, s,
+                       a, KT, NTT);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -862,6 +902,10 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm: SWIGLU needs N %% 32 == 0");
     UMV_CHECK(!a.norm_w || (a.M <= 16 && a.K <= SK_WAVES * SK_XMAX * 32), UMV_ERR_UNSUPPORTED,
               "gemm: fused RMSNorm needs M <= 16 and K <= %d (got M=%d K=%d)", SK_WAVES * SK_XMAX * 32, a.M, a.K);
+    UMV_CHECK(a.k_splits <= 1 || (a.M <= 64 && !a.norm_w && !(a.epilogue & UMV_EPI_SWIGLU) && a.tile_rows % 16 == 0 && a.split_stride > 0),
+              UMV_ERR_UNSUPPORTED, "gemm: split-K (k_splits=%d) is a decode mode: M <= 64, 16-row image, no SwiGLU / fused norm, "
+              "split_stride > 0", a.k_splits);
+    UMV_CHECK(a.k_splits <= 64, UMV_ERR_ARG, "gemm: k_splits %d > 64", a.k_splits);
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 31) / 32;
@@ -872,6 +916,13 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     const int NTT = (a.N + TH - 1) / TH;
     static int skinny_max = -1;   // tuning only: UMV_GEMM_SKINNY_MAX=<M> (rows up to which the weight-streaming kernel is used)
     if (skinny_max < 0) { const char* e = getenv("UMV_GEMM_SKINNY_MAX"); skinny_max = e ? atoi(e) : 64; }
+    if (a.k_splits > 1) {
+        // split-K decode GEMM: 4 n-tiles per workgroup share every x fragment (x re-reads from L2 drop 4x against the
+        // one-tile workgroups), the K range is cut k_splits ways to keep >= 256 workgroups, partial sums go to fp32
+        if (a.M <= 16) return launch_skinny<1, 4, 2, true, 0>(a, KT, NTT, s);
+        if (a.M <= 32) return launch_skinny<2, 4, 2, false, 0>(a, KT, NTT, s);
+        return launch_skinny<4, 4, 1, false, 0>(a, KT, NTT, s);
+    }
     if (a.M <= 64 && (a.M <= skinny_max || TH != 16)) {
         const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
         if (a.M <= 16) {
@@ -879,6 +930,11 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
             if (a.norm_w) return two ? launch_skinny<1, 2, 4, true, 16>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, 16>(a, KT, NTT, s);
             return two ? launch_skinny<1, 2, 4, true, 0>(a, KT, NTT, s) : launch_skinny<1, 1, 8, true, 0>(a, KT, NTT, s);
         }
+        // M > 16: every workgroup re-reads all of x from L2, so wide-N GEMMs take 4 n-tiles per workgroup (x : weight bytes
+        // = M : 64); UMV_GEMM_SKINNY_NT=2 restores the 2-tile kernels (tuning only)
+        static int nt4 = -1;
+        if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : 1; }
+        if (two && nt4 && TH == 16) return a.M <= 32 ? launch_skinny<2, 4, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 4, 1, false, 0>(a, KT, NTT, s);
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }

@@ -78,6 +78,19 @@ class DecodeSession:
         if exact and not hasattr(w, "decode_copies"):
             w.decode_copies = [(lw.qkv.for_decode(), lw.o.for_decode(), lw.down.for_decode()) for lw in w.und]
         self.dec = w.decode_copies if exact else [(lw.qkv, lw.o, lw.down) for lw in w.und]
+        # split-K mode for the N = 3584 / 4608 GEMMs (bf16 weights): "qkv,o,down" split counts, "0" = off, "auto" by batch
+        sk = os.environ.get("UMV_DECODE_SPLITK", "auto")
+        self.sk = None
+        if sk not in ("0", "") and B <= 64:
+            if sk == "auto":
+                # measured on MI355X (bench.py --batch B): B=8 3.448 -> 3.426 ms (noise), 12: 3.72 -> 3.59, 16: 4.09 -> 3.85,
+                # 32: 5.48 -> 4.67, 64: 9.07 -> 6.35; more splits are slower (4,4,8: 4.95 at B=32; 4,4,16: 5.22)
+                sk = "3,4,4" if B > 8 else "0"
+            if sk != "0":
+                self.sk = tuple(int(v) for v in sk.split(","))
+                assert len(self.sk) == 3 and all(1 < v <= 64 for v in self.sk)
+                self.p_qkv = torch.empty((self.sk[0], B, (nq + 2 * nkv) * hd), dtype=torch.float32, device=dev)
+                self.p_h = torch.empty((max(self.sk[1], self.sk[2]), B, H), dtype=torch.float32, device=dev)
         self.do_sample, self.temperature, self.seed = bool(do_sample), float(temperature), int(seed)
         self.steps_done = 0
         self.graph = None
@@ -99,7 +112,42 @@ class DecodeSession:
         if self.prefetch:
             torch.cuda.current_stream().wait_stream(self.pf_stream)
 
+    def _step_splitk(self):
+        """Same step with the N=3584/4608 GEMMs in split-K mode: 4 n-tiles per workgroup share each x fragment and the
+        fp32 partial sums are finished by the kernel that follows anyway (qkv_post; residual add + the next RMSNorm)."""
+        cfg, w, c = self.cfg, self.llm.w, self.cache
+        nq, nkv, hd = cfg.heads, cfg.kv_heads, cfg.head_dim
+        L = cfg.layers
+        sq, so, sd = self.sk
+        self.in_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
+        ops.embed_gather(w.embed, self.ids, out=self.seq)
+        ops.rmsnorm(self.seq, w.und[0].in_norm, cfg.rms_eps, out=self.x)
+        for l in range(L):
+            lw = w.und[l]
+            ops.gemm_splitk(self.x, lw.qkv, self.p_qkv, sq)
+            ops.qkv_post(None, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd, cfg.rms_eps,
+                         lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin, partials=self.p_qkv, bias=lw.qkv.bias)
+            ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
+                          self.nsplit, self.ws)
+            ops.gemm_splitk(self.o, lw.o, self.p_h[:so], so)
+            ops.residual_rmsnorm(self.p_h[:so], self.seq, lw.post_norm, cfg.rms_eps, out=self.x)
+            ops.gemm(self.x, lw.gate_up, out=self.act)
+            ops.gemm_splitk(self.act, lw.down, self.p_h[:sd], sd)
+            last = l + 1 == L
+            ops.residual_rmsnorm(self.p_h[:sd], self.seq, w.norm if last else w.und[l + 1].in_norm, cfg.rms_eps,
+                                 out=self.hn if last else self.x)
+        ops.gemm(self.hn, w.lm_head, out=self.logits)
+        if self.do_sample:
+            ops.sample(self.logits, self.temperature, self.seed, step=self.step_idx, out=self.ids)
+        else:
+            ops.argmax(self.logits, out=self.ids)
+        self.pred_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
+        ops.decode_advance(self.tok_slot, self.tok_pos, self.kv_len)
+        self.step_idx.add_(1)
+
     def _step(self):
+        if self.sk is not None:
+            return self._step_splitk()
         cfg, w, c = self.cfg, self.llm.w, self.cache
         nq, nkv, hd = cfg.heads, cfg.kv_heads, cfg.head_dim
         MB = 1 << 20

@@ -318,13 +318,55 @@ class KVSlab:
                     v_seg_stride=self.nkv * self.hd * self.cap, v_head_stride=self.hd * self.cap, v_d_stride=self.cap)
 
 
-def qkv_post(qkv, q_out, slab, tok_seg, tok_slot, tok_pos, nq, nkv, hd, eps=1e-6, q_norm=None, k_norm=None,
-             q_norm_gen=None, k_norm_gen=None, expert=None, cos_tab=None, sin_tab=None, T=None, fp32_chain=False):
+def gemm_splitk(x, lin, partials, k_splits, *, M=None):
+    """Split-K decode GEMM (M <= 64): raw fp32 partial sums [k_splits, rows, N] into `partials`; the consumer
+    (qkv_post(partials=...) / residual_rmsnorm) adds the splits and finishes the row."""
     lib = _lib.load()
-    _req(qkv, BF16, "qkv")
-    T = qkv.shape[0] if T is None else T
+    _req(x, BF16, "x")
+    _req(partials, torch.float32, "partials")
+    M = x.shape[0] if M is None else M
+    assert partials.dim() == 3 and partials.shape[0] == k_splits and partials.shape[2] == lin.N and partials.is_contiguous()
+    assert lin.th == 16 and not lin.swiglu
+    a = GemmArgs(x=x.data_ptr(), ldx=x.stride(0), wp=lin.wp.data_ptr(), out=partials.data_ptr(), ldo=lin.N, M=M, N=lin.N, K=lin.K,
+                 epilogue=0, tile_rows=0, k_splits=k_splits, split_stride=partials.stride(0))
+    if lin.w8 is not None:   # e4m3 image: same split, same consumers
+        a.wp, a.w_scale = lin.w8.data_ptr(), lin.scale.data_ptr()
+        check(lib.umv_gemm_fp8w(C.byref(a), _stream()), "umv_gemm_fp8w")
+    else:
+        check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
+    return partials
+
+
+def residual_rmsnorm(partials, seq, w, eps, out):
+    """seq = bf16(bf16(sum_s partials[s]) + seq) in place; out = RMSNorm(seq) * w.  partials [S, T, H] fp32."""
+    lib = _lib.load()
+    _req(partials, torch.float32, "partials")
+    _req(seq, BF16, "seq")
+    S, T, H = partials.shape
+    assert seq.shape == (T, H) and seq.is_contiguous() and out.is_contiguous() and partials.is_contiguous()
+    check(lib.umv_residual_rmsnorm_bf16(_p(partials), S, partials.stride(0), partials.stride(1), _p(seq), _p(w), _p(out), T, H, eps,
+                                        _stream()), "umv_residual_rmsnorm_bf16")
+    return out
+
+
+def qkv_post(qkv, q_out, slab, tok_seg, tok_slot, tok_pos, nq, nkv, hd, eps=1e-6, q_norm=None, k_norm=None,
+             q_norm_gen=None, k_norm_gen=None, expert=None, cos_tab=None, sin_tab=None, T=None, fp32_chain=False,
+             partials=None, bias=None):
+    """partials (fp32 [S, T, (nq+2nkv)*hd]) + bias: take the QKV row from a split-K GEMM instead of `qkv`."""
+    lib = _lib.load()
+    if partials is None:
+        _req(qkv, BF16, "qkv")
+        T = qkv.shape[0] if T is None else T
+    else:
+        _req(partials, torch.float32, "partials")
+        T = partials.shape[1] if T is None else T
     a = QkvPostArgs(
-        qkv=qkv.data_ptr(), q_out=q_out.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(),
+        qkv=None if qkv is None else qkv.data_ptr(),
+        qkv_partials=None if partials is None else partials.data_ptr(),
+        n_splits=0 if partials is None else partials.shape[0],
+        split_stride=0 if partials is None else partials.stride(0),
+        qkv_bias=None if bias is None else bias.data_ptr(),
+        q_out=q_out.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(),
         tok_seg=tok_seg.data_ptr(), tok_slot=tok_slot.data_ptr(),
         tok_pos=None if tok_pos is None else tok_pos.data_ptr(),
         expert=None if expert is None else expert.data_ptr(),
