@@ -85,7 +85,8 @@ class DecodeSession:
             if sk == "auto":
                 # measured on MI355X (bench.py --batch B): B=8 3.448 -> 3.426 ms (noise), 12: 3.72 -> 3.59, 16: 4.09 -> 3.85,
                 # 32: 5.48 -> 4.67, 64: 9.07 -> 6.35; more splits are slower (4,4,8: 4.95 at B=32; 4,4,16: 5.22)
-                sk = "3,4,4" if B > 8 else "0"
+                # e4m3 weights: x is as many bytes as the weights already at B=8, the split pays there too (2.63 -> 2.52 ms)
+                sk = "3,4,4" if (B > 8 or w.fp8) else "0"
             if sk != "0":
                 self.sk = tuple(int(v) for v in sk.split(","))
                 assert len(self.sk) == 3 and all(1 < v <= 64 for v in self.sk)
