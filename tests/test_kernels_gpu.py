@@ -295,3 +295,19 @@ def test_attention_decode_split(ops):
     _attn_case(ops, 28, 4, 128, [1] * 8, [1061, 1070, 33, 1, 500, 777, 1572, 64], causal=True, nsplit=1)
     _attn_case(ops, 28, 4, 128, [1] * 8, [1061, 1070, 33, 1, 500, 777, 1572, 64], causal=True, nsplit=8)
     _attn_case(ops, 2, 1, 128, [1, 1], [20, 45], causal=True, nsplit=4)
+
+
+def test_f2bf_exhaustive(ops):
+    """The fp32 -> bf16 rounding every kernel uses (common.h f2bf / pack2bf on v_cvt_pk_bf16_f32) against torch's own
+    conversion over ALL 2^32 fp32 bit patterns (through umv_cast_pad_f32_bf16): identical bits for every non-NaN input
+    (round to nearest even, overflow to inf, denormals kept), NaN in -> NaN out."""
+    chunk = 1 << 26
+    base = torch.arange(chunk, dtype=torch.int64, device="cuda")
+    for c in range((1 << 32) // chunk):
+        bits = (base + c * chunk).to(torch.int32) if c * chunk < (1 << 31) else (base + c * chunk - (1 << 32)).to(torch.int32)
+        x = bits.view(torch.float32).view(chunk // 4096, 4096)
+        got = ops.cast_pad(x, 4096).view(torch.int16)
+        ref = x.to(torch.bfloat16).view(torch.int16)
+        nan = torch.isnan(x)
+        assert torch.equal(got[~nan], ref[~nan]), f"chunk {c}"
+        assert torch.isnan(got.view(torch.bfloat16)[nan].float()).all()

@@ -14,17 +14,17 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (same result as torch's .to(bfloat16) for finite values; NaN stays NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16 on the gfx950 converter (v_cvt_pk_bf16_f32: one instruction for two values instead
+// of ~6 integer ops each).  Same bits as torch's .to(bfloat16) for every non-NaN input - checked over all 2^32 patterns in
+// tests/test_kernels_gpu.py::test_f2bf_exhaustive - and a quiet NaN for NaN.
+typedef __attribute__((ext_vector_type(2))) __bf16 umv_bf16x2_hw;
+typedef __attribute__((ext_vector_type(2))) float umv_f32x2;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
 
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    umv_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, umv_bf16x2_hw));
 }
 
 // 1/sqrt(x) with correctly rounded sqrt and divide (what torch.rsqrt does on CPU)
