@@ -141,12 +141,12 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+        const float alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
         float ps = 0.f;
         bf16x8 pf;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float p = exp2f(sc[i] - m_use);   // exp2(-inf) = 0
+            float p = umv_exp2(sc[i] - m_use);   // exp2(-inf) = 0
             bf16_t pb = f2bf(p);
             ps += p;
             pf[i] = (short)pb;
@@ -331,12 +331,12 @@ __global__ __launch_bounds__(256) void attn_shared_kernel(umv_attn_args a, float
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+            const float alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
             float ps = 0.f;
             bf16x8 pf;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float p = exp2f(sc[i] - m_use);
+                float p = umv_exp2(sc[i] - m_use);
                 ps += p;
                 pf[i] = (short)f2bf(p);
             }
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
         l = base[lane * (HD + 4) + HD + 1];
     }
     const float M = wave_max(m);
-    const float wgt = (m == -INFINITY) ? 0.f : exp2f(m - M);
+    const float wgt = (m == -INFINITY) ? 0.f : umv_exp2(m - M);
     const float L = wave_sum(wgt * l);
     constexpr int PER = (HD + 63) / 64;
     float acc[PER];

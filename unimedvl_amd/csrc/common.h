@@ -27,6 +27,10 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, umv_bf16x2_hw));
 }
 
+// 2^x on the hardware unit alone (v_exp_f32, ~1 ulp; results below 2^-126 flush to 0, exp2(-inf) = 0): the softmax
+// weights of the attention kernels.  exp2f() wraps the same instruction in ~5 more VALU ops of denormal handling.
+__device__ __forceinline__ float umv_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // 1/sqrt(x) with correctly rounded sqrt and divide (what torch.rsqrt does on CPU)
 __device__ __forceinline__ float rsqrt_ieee(float x) { return __fdiv_rn(1.0f, __fsqrt_rn(x)); }
 

@@ -16,14 +16,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ----------------------------------------------------------------------------- epilogue math
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+    // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3))), with tanh(u) = 1 - 2/(2^(2u*log2 e) + 1)
+    // on v_exp_f32 / v_rcp_f32 (abs error ~1e-7, far below the bf16 rounding that follows; libm's tanhf is ~40 VALU ops)
     const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
     const float kKappa = 0.044715f;
     float x3 = x * x * x;
     float inner = kBeta * (x + kKappa * x3);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    float e = __builtin_amdgcn_exp2f(fminf(inner * 2.8853900817779268f, 126.0f));   // 2^(2u log2 e), clamped: no inf/inf
+    float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return 0.5f * x * (1.0f + th);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (relative error ~2e-7 before the bf16 rounding)
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(-x * 1.4426950408889634f, 126.0f)));
+}
 
 struct EpiCtx {
     const bf16_t* bias;
