@@ -14,6 +14,10 @@
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 
+// attention_prefill.hip: the nsplit == 1 path with K / V^T shared through LDS (bit-identical results)
+bool umv_attn_prefill_enabled();
+int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s);
+
 __device__ __forceinline__ bf16x8 mask_keys(bf16x8 v, int nvalid) {
     // keep the first nvalid (0..8) bf16 elements, zero the rest
     bf16x8 o;
@@ -209,168 +213,6 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     }
 }
 
-// ----------------------------------------------------------------------------- prefill variant: K / V^T shared through LDS
-// attn_kernel lets every wave stream its own K / V^T fragments from L2: with 64-128 q-tiles per (segment, kv head) that is
-// 64-128x the K/V bytes through L2->L1 (ViT: 2.4 GB per layer, 12 TB/s - the measured ceiling of that path).  Here the 4
-// waves of a workgroup (4 q-tiles of the same segment / kv head) share each 64-key stage: LDS-DMA gathers the K and V^T
-// fragments straight into MFMA fragment order (every lane supplies its own source address, the destination is lane-linear,
-// so the ds_read_b128 of the consumers are conflict free), double buffered, one barrier per stage.  Same arithmetic, same
-// order of operations per row as attn_kernel: results are bit-identical.
-__device__ __attribute__((aligned(16))) const uint32_t g_attn_zero_page[4] = {0, 0, 0, 0};
-typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
-
-template <int HD>
-__global__ __launch_bounds__(256) void attn_shared_kernel(umv_attn_args a, float scale_log2e) {
-    constexpr int KS = (HD + 31) / 32;
-    constexpr int DT = (HD + 15) / 16;
-    constexpr int FK = 2 * KS, FB = FK + DT;   // fragments (1 KiB each) per 32-key block: K then V^T
-    constexpr int NB = 2;                      // 32-key blocks per stage
-    constexpr int STAGE = NB * FB * 1024;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    const int G = a.nq / a.nkv;
-    const int QPT = 16 / G > 0 ? 16 / G : 1;
-    const int s = blockIdx.z;
-    const int kh = blockIdx.y;
-    const int qt0 = blockIdx.x * 4;
-    const int qt = qt0 + wave;
-    const int q0 = a.cu_q[s];
-    const int Lq = a.cu_q[s + 1] - q0;
-    const int Lk = a.kv_len[s];
-    if (qt0 * QPT >= Lq || Lk <= 0) return;    // uniform over the workgroup
-    const bool active = qt * QPT < Lq;
-
-    const int ql = j / G, hg = j % G;
-    const int qi = qt * QPT + ql;
-    const bool rvalid = active && (j < G * QPT) && (qi < Lq);
-    const int head = kh * G + hg;
-    const int limit = a.causal ? (Lk - Lq + qi) : (Lk - 1);
-
-    bf16x8 qf[KS];
-    {
-        const bf16_t* qp = a.q + ((int64_t)(q0 + (rvalid ? qi : 0)) * a.nq + head) * HD;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d = ks * 32 + g * 8;
-            qf[ks] = (rvalid && d < HD) ? ldg_frag(qp + d) : zero_frag();
-        }
-    }
-    // key ranges: the workgroup walks up to the largest causal limit of its tiles, a wave computes up to its own
-    int blk_end = Lk, my_end = Lk;
-    if (a.causal) {
-        const int last_blk = min(Lq - 1, (qt0 + 3) * QPT + QPT - 1);
-        blk_end = min(Lk, Lk - Lq + last_blk + 1);
-        const int last_q = min(Lq - 1, qt * QPT + QPT - 1);
-        my_end = min(Lk, Lk - Lq + last_q + 1);
-    }
-    if (!active) my_end = 0;
-    const int nstages = (blk_end + 32 * NB - 1) / (32 * NB);
-    const bf16_t* kbase = a.k_slab + s * a.k_seg_stride + kh * a.k_head_stride;
-    const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero_page);
-    const int cap = (int)a.v_d_stride;
-
-    auto stage = [&](int sidx, int buf) {
-        for (int f = wave; f < NB * FB; f += 4) {
-            const int b = f / FB, ff = f - b * FB;
-            const int kb = (sidx * NB + b) * 32;
-            const bf16_t* p;
-            if (ff < FK) {     // K fragment (t, ks): row i of tile t <-> key kb + (i>>2)*8 + t*4 + (i&3)
-                const int t = ff / KS, ks = ff - t * KS;
-                const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-                const int d = ks * 32 + g * 8;
-                p = (d < HD) ? kbase + (int64_t)min(key, Lk - 1) * HD + d : zero;
-            } else {           // V^T fragment dt: row d = dt*16 + j, keys kb + g*8 .. +8
-                const int d = (ff - FK) * 16 + j;
-                const int col = kb + g * 8;
-                p = (d < HD && col + 8 <= cap) ? vbase + (int64_t)d * a.v_d_stride + col : zero;
-            }
-            __builtin_amdgcn_global_load_lds((const void*)p, (attn_lds_ptr_t)(smem + buf * STAGE + f * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x4 o[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    stage(0, 0);
-    for (int sidx = 0; sidx < nstages; ++sidx) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my part of stage sidx has landed
-        __builtin_amdgcn_s_barrier();                            // ... everyone's; and everyone is done with stage sidx-1
-        if (sidx + 1 < nstages) stage(sidx + 1, (sidx + 1) & 1); // overlaps the math below
-        const char* sb = smem + (sidx & 1) * STAGE;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int kb = (sidx * NB + b) * 32;
-            if (kb >= my_end) continue;
-            const char* fb = sb + b * FB * 1024 + lane * 16;
-            f32x4 st[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    st[t] = mfma16(*reinterpret_cast<const bf16x8*>(fb + (t * KS + ks) * 1024), qf[ks], st[t]);
-            }
-            float sc[8];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kb + g * 8 + t * 4 + r;
-                    float v = st[t][r] * scale_log2e;
-                    v = (key <= limit && key < my_end) ? v : -INFINITY;
-                    sc[t * 4 + r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
-            float ps = 0.f;
-            bf16x8 pf;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float p = umv_exp2(sc[i] - m_use);
-                ps += p;
-                pf[i] = (short)f2bf(p);
-            }
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
-            l_run = l_run * alpha + ps;
-            m_run = m_new;
-            const bool partial = kb + 32 > Lk;
-            const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
-                if (partial) v = mask_keys(v, nvalid);
-                f32x4 acc = o[dt];
-                acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
-                o[dt] = mfma16(v, pf, acc);
-            }
-        }
-    }
-    if (!rvalid) return;
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    bf16_t* op = a.out + ((int64_t)(q0 + qi) * a.nq + head) * HD;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d = dt * 16 + g * 4;
-        if (d + 3 < HD) {
-            u32x2 pk;
-            pk.x = pack2bf(o[dt].x * inv, o[dt].y * inv);
-            pk.y = pack2bf(o[dt].z * inv, o[dt].w * inv);
-            *reinterpret_cast<u32x2*>(op + d) = pk;
-        }
-    }
-}
-
 // Merge the nsplit partial (O, m, l) triples of one (token, head) row.  One wavefront per row; the
 // (m, l) pairs are read by lanes 0..nsplit-1 in one go and the weighted O sums use independent,
 // fully unrolled loads (the kernel is pure latency otherwise).
@@ -434,22 +276,8 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     dim3 grid((qtiles + 3) / 4, a.nkv * a.nsplit, a.nseg), block(256);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
-    static int share = -1;   // UMV_ATTN_SHARED=0 falls back to the per-wave streaming kernel (tuning / A-B only)
-    if (share < 0) { const char* e = getenv("UMV_ATTN_SHARED"); share = (e && atoi(e) == 0) ? 0 : 1; }
-    if (share && a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72)) {
-        dim3 sgrid((qtiles + 3) / 4, a.nkv, a.nseg);
-        if (a.hd == 128) {
-            constexpr int lds = 2 * 2 * (2 * 4 + 8) * 1024;
-            static bool attr = false;
-            if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_shared_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-            hipLaunchKernelGGL((attn_shared_kernel<128>), sgrid, block, lds, s, a, scale_log2e);
-        } else {
-            constexpr int lds = 2 * 2 * (2 * 3 + 5) * 1024;
-            hipLaunchKernelGGL((attn_shared_kernel<72>), sgrid, block, lds, s, a, scale_log2e);
-        }
-        UMV_LAUNCH_CHECK();
-        return UMV_OK;
-    }
+    if (a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72) && umv_attn_prefill_enabled())
+        return umv_attn_prefill_launch(a, qtiles, scale_log2e, s);
     if (a.hd == 128)
         hipLaunchKernelGGL((attn_kernel<128>), grid, block, 0, s, a, scale_log2e);
     else if (a.hd == 72)

@@ -1,0 +1,249 @@
+// Prefill attention for libunimedvl_hip (gfx950): the nsplit == 1 path of umv_attn_varlen for hd 128 / 72
+// (flash_attn_varlen_func at qwen2_navit.py:605-614, siglip_navit.py:232-241).
+//
+// attention.hip's attn_kernel lets every wave stream its own K / V^T fragments from L2: with 64-128 q-tiles per
+// (segment, kv head) that is 64-128x the K/V bytes through L2->L1 (ViT: 2.4 GB per layer = 12 TB/s, the measured ceiling
+// of that path).  Here the 4 waves of a workgroup take TQ q-tiles each (4*TQ tiles of the same segment / kv head) and
+// share every 64-key stage through LDS:
+//   * LDS-DMA gathers the K and V^T fragments straight into MFMA fragment order (every lane supplies its own source
+//     address, the destination is lane-linear, so the consumers' ds_read_b128 are conflict free), double buffered, one
+//     barrier per stage;
+//   * a fragment read from LDS feeds TQ MFMAs (one per q-tile of the wave): half the LDS bytes per flop at TQ = 2;
+//   * interior blocks skip the per-element causal / length masks, and the O rescale is skipped once the running maxima
+//     have settled (alpha == 1 in every lane) - both exact.
+// Per row the arithmetic and its order are those of attn_kernel: results are bit-identical (tools/attn_ab.py).
+#include "common.h"
+#include "../../include/unimedvl_hip.h"
+#include <stdlib.h>
+
+__device__ __attribute__((aligned(16))) const uint32_t g_attn_zero_page[4] = {0, 0, 0, 0};
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+
+__device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // keep the first nvalid (0..8) elements
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = j < nvalid ? v[j] : (short)0;
+    return o;
+}
+
+template <int HD, int TQ>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, float scale_log2e) {
+    constexpr int KS = (HD + 31) / 32;
+    constexpr int DT = (HD + 15) / 16;
+    constexpr int FK = 2 * KS, FB = FK + DT;   // fragments (1 KiB each) per 32-key block: K then V^T
+    constexpr int NB = 2;                      // 32-key blocks per stage
+    constexpr int STAGE = NB * FB * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int G = a.nq / a.nkv;
+    const int QPT = 16 / G > 0 ? 16 / G : 1;
+    const int s = blockIdx.z;
+    const int kh = blockIdx.y;
+    const int qt_wg = blockIdx.x * 4 * TQ;      // first q-tile of the workgroup
+    const int q0 = a.cu_q[s];
+    const int Lq = a.cu_q[s + 1] - q0;
+    const int Lk = a.kv_len[s];
+    if (qt_wg * QPT >= Lq || Lk <= 0) return;   // uniform over the workgroup
+
+    const int ql = j / G, hg = j % G;
+    const int head = kh * G + hg;
+    int qi[TQ], limit[TQ], my_end[TQ], min_limit[TQ];
+    bool rvalid[TQ];
+    bf16x8 qf[TQ][KS];
+    int wave_end = 0;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const int qt = qt_wg + wave * TQ + u;
+        const bool active = qt * QPT < Lq;
+        qi[u] = qt * QPT + ql;
+        rvalid[u] = active && (j < G * QPT) && (qi[u] < Lq);
+        limit[u] = a.causal ? (Lk - Lq + qi[u]) : (Lk - 1);     // bottom-right aligned causal mask
+        min_limit[u] = a.causal ? (Lk - Lq + qt * QPT) : (Lk - 1);
+        int e = Lk;
+        if (a.causal) e = min(Lk, Lk - Lq + min(Lq - 1, qt * QPT + QPT - 1) + 1);
+        my_end[u] = active ? e : 0;
+        wave_end = max(wave_end, my_end[u]);
+        const bf16_t* qp = a.q + ((int64_t)(q0 + (rvalid[u] ? qi[u] : 0)) * a.nq + head) * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            qf[u][ks] = (rvalid[u] && d < HD) ? ldg_frag(qp + d) : zero_frag();
+        }
+    }
+    int blk_end = Lk;
+    if (a.causal) {
+        const int last_blk = min(Lq - 1, (qt_wg + 4 * TQ - 1) * QPT + QPT - 1);
+        blk_end = min(Lk, Lk - Lq + last_blk + 1);
+    }
+    const int nstages = (blk_end + 32 * NB - 1) / (32 * NB);
+    const bf16_t* kbase = a.k_slab + s * a.k_seg_stride + kh * a.k_head_stride;
+    const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero_page);
+    const int cap = (int)a.v_d_stride;
+
+    auto stage = [&](int sidx, int buf) {
+        for (int f = wave; f < NB * FB; f += 4) {
+            const int b = f / FB, ff = f - b * FB;
+            const int kb = (sidx * NB + b) * 32;
+            const bf16_t* p;
+            if (ff < FK) {     // K fragment (t, ks): row i of tile t <-> key kb + (i>>2)*8 + t*4 + (i&3)
+                const int t = ff / KS, ks = ff - t * KS;
+                const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
+                const int d = ks * 32 + g * 8;
+                p = (d < HD) ? kbase + (int64_t)min(key, Lk - 1) * HD + d : zero;
+            } else {           // V^T fragment dt: row d = dt*16 + j, keys kb + g*8 .. +8
+                const int d = (ff - FK) * 16 + j;
+                const int col = kb + g * 8;
+                p = (d < HD && col + 8 <= cap) ? vbase + (int64_t)d * a.v_d_stride + col : zero;
+            }
+            __builtin_amdgcn_global_load_lds((const void*)p, (attn_lds_ptr_t)(smem + buf * STAGE + f * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 o[TQ][DT];
+    float m_run[TQ], l_run[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        m_run[u] = -INFINITY;
+        l_run[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    stage(0, 0);
+    for (int sidx = 0; sidx < nstages; ++sidx) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my part of stage sidx has landed
+        __builtin_amdgcn_s_barrier();                            // ... everyone's; and everyone is done with stage sidx-1
+        if (sidx + 1 < nstages) stage(sidx + 1, (sidx + 1) & 1); // overlaps the math below
+        const char* sb = smem + (sidx & 1) * STAGE;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int kb = (sidx * NB + b) * 32;
+            if (kb >= wave_end) continue;
+            const char* fb = sb + b * FB * 1024 + lane * 16;
+            // ---- S^T = K Q^T : one K fragment from LDS feeds the wave's TQ tiles
+            f32x4 st[TQ][2];
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) st[u][0] = st[u][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(fb + (t * KS + ks) * 1024);
+#pragma unroll
+                    for (int u = 0; u < TQ; ++u) st[u][t] = mfma16(kf, qf[u][ks], st[u][t]);
+                }
+            bf16x8 pf[TQ];
+            float alpha[TQ];
+            bool rescale = false;
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) {
+                float sc[8];
+                float mx = -INFINITY;
+                const bool interior = kb + 32 <= my_end[u] && kb + 31 <= min_limit[u];   // wave uniform
+                if (interior) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = st[u][t][r] * scale_log2e;
+                            sc[t * 4 + r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kb + g * 8 + t * 4 + r;
+                            float v = st[u][t][r] * scale_log2e;
+                            v = (key <= limit[u] && key < my_end[u]) ? v : -INFINITY;
+                            sc[t * 4 + r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[u], mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                alpha[u] = (m_run[u] == -INFINITY) ? 0.f : umv_exp2(m_run[u] - m_use);
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p = umv_exp2(sc[i] - m_use);   // exp2(-inf) = 0
+                    ps += p;
+                    pf[u][i] = (short)f2bf(p);
+                }
+                ps += __shfl_xor(ps, 16, 64);
+                ps += __shfl_xor(ps, 32, 64);
+                l_run[u] = l_run[u] * alpha[u] + ps;
+                m_run[u] = m_new;
+                rescale = rescale || __any(alpha[u] != 1.0f);
+            }
+            // ---- O^T += V^T P^T : one V^T fragment from LDS feeds the TQ tiles
+            const bool partial = kb + 32 > Lk;
+            const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
+                if (partial) v = attn_mask_keys(v, nvalid);
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) {
+                    f32x4 acc = o[u][dt];
+                    if (rescale) { acc.x *= alpha[u]; acc.y *= alpha[u]; acc.z *= alpha[u]; acc.w *= alpha[u]; }
+                    o[u][dt] = mfma16(v, pf[u], acc);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        if (!rvalid[u]) continue;
+        const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
+        bf16_t* op = a.out + ((int64_t)(q0 + qi[u]) * a.nq + head) * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g * 4;
+            if (d + 3 < HD) {
+                u32x2 pk;
+                pk.x = pack2bf(o[u][dt].x * inv, o[u][dt].y * inv);
+                pk.y = pack2bf(o[u][dt].z * inv, o[u][dt].w * inv);
+                *reinterpret_cast<u32x2*>(op + d) = pk;
+            }
+        }
+    }
+}
+
+// UMV_ATTN_SHARED=0 falls back to the per-wave streaming kernel; UMV_ATTN_TQ=1|2 picks the q-tiles per wave (A/B only)
+bool umv_attn_prefill_enabled() {
+    static int share = -1;
+    if (share < 0) { const char* e = getenv("UMV_ATTN_SHARED"); share = (e && atoi(e) == 0) ? 0 : 1; }
+    return share != 0;
+}
+
+template <int HD, int TQ>
+static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
+    constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
+    constexpr int lds = 2 * 2 * (2 * KS + DT) * 1024;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    dim3 grid((qtiles + 4 * TQ - 1) / (4 * TQ), a.nkv, a.nseg);
+    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ>), grid, dim3(256), lds, s, a, scale_log2e);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
+    static int tq = -1;
+    if (tq < 0) { const char* e = getenv("UMV_ATTN_TQ"); tq = e ? atoi(e) : 0; }
+    // two q-tiles per wave only when that still leaves >= 2 workgroups per CU (measured: LLM prefill 496 -> 413 us, flow pass
+    // 96 -> 83, ViT 152 -> 144; but 34-token text prefill 52 -> 73 us with only 96 workgroups)
+    const bool two = tq == 2 || (tq != 1 && (long)((qtiles + 7) / 8) * a.nkv * a.nseg >= 512);
+    if (a.hd == 128) return two ? launch_prefill<128, 2>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1>(a, qtiles, scale_log2e, s);
+    return two ? launch_prefill<72, 2>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1>(a, qtiles, scale_log2e, s);
+}
