@@ -1,0 +1,66 @@
+"""Continuous batching (unimedvl_amd/serving.py): more requests than slots, ragged contexts, per-request EOS / token
+budgets, slots refilled in flight.  Every request must get exactly the answer that one-request-at-a-time greedy decoding
+(Bagel.chat, the mirror of bagel.py:1321-1392) gives it: samples are independent rows of every kernel, whichever slot and
+neighbours a request lands on."""
+import pytest
+import torch
+
+from conftest import NEW_TOKEN_IDS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(tiny_weights):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    cfg, sd, _, _ = tiny_weights
+    return Bagel(UniMedVLConfig.from_dict(cfg), lambda n: sd[n], device="cuda", visual_gen=False)
+
+
+def _requests(n):
+    g = torch.Generator().manual_seed(21)
+    reqs = []
+    for i in range(n):
+        h, w = [(42, 56), (28, 70), (56, 56), (42, 42)][i % 4]
+        images = [] if i % 5 == 4 else [torch.randn(3, h, w, generator=g).clamp(-1, 1)]
+        if i % 7 == 3:
+            images.append(torch.randn(3, 28, 28, generator=g).clamp(-1, 1))
+        prompt = " ".join(str(int(v)) for v in torch.randint(5, 290, (2 + i % 6,), generator=g))
+        reqs.append((images, prompt))
+    return reqs
+
+
+@pytest.mark.parametrize("slots,check_every,use_graph", [(3, 4, True), (8, 3, True), (2, 5, False)])
+def test_continuous_batching_matches_single_requests(model, slots, check_every, use_graph):
+    from oracle.toy_tokenizer import ToyTokenizer
+    from unimedvl_amd.serving import ContinuousBatcher
+    tok = ToyTokenizer(NEW_TOKEN_IDS)
+    reqs = _requests(7)
+    budgets = [6, 3, 6, 5, 6, 2, 6]
+    ident = lambda x: x   # noqa: E731  (images are already [3,H,W] tensors in [-1,1])
+    want = []
+    for (images, prompt), nb in zip(reqs, budgets):
+        want.append(model.chat(tok, NEW_TOKEN_IDS, ident, images, prompt, max_length=nb + 1))
+    srv = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, ident, slots=slots, max_context=256, max_new_tokens=8,
+                            check_every=check_every, use_graph=use_graph)
+    rids = [srv.submit(images, prompt, max_new_tokens=nb) for (images, prompt), nb in zip(reqs, budgets)]
+    got = srv.run()
+    assert sorted(got) == sorted(rids)
+    for rid, w in zip(rids, want):
+        assert got[rid] == w, (rid, got[rid], w)
+    assert srv.stats["prefills"] == 7 and srv.stats["tokens"] == sum(len(tok.encode(w)) for w in want)
+
+
+def test_batcher_rejects_oversized_requests(model):
+    from oracle.toy_tokenizer import ToyTokenizer
+    from unimedvl_amd.serving import ContinuousBatcher
+    tok = ToyTokenizer(NEW_TOKEN_IDS)
+    srv = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, lambda x: x, slots=2, max_context=16, max_new_tokens=4)
+    with pytest.raises(ValueError, match="reserve"):
+        srv.submit(None, "5 6", max_new_tokens=9)
+    srv.submit(None, " ".join(["7"] * 40))
+    with pytest.raises(ValueError, match="max_context"):
+        srv.run()

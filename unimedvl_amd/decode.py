@@ -224,6 +224,20 @@ class DecodeSession:
                 self._step()
             self.steps_done += 1
 
+    # ---- continuous batching support (serving.py): the captured step reads these from device memory, so a slot can be
+    # re-pointed at a new request between replays without re-capturing
+    def set_slot(self, b, token, kv_len, pos):
+        """Sample b continues from `token` with `kv_len` tokens already in its cache segment and rope position `pos`."""
+        self.ids[b:b + 1].fill_(int(token))
+        self.tok_slot[b:b + 1].fill_(int(kv_len))
+        self.kv_len[b:b + 1].fill_(int(kv_len) + 1)
+        self.tok_pos[b:b + 1].fill_(int(pos))
+
+    def rewind_outputs(self):
+        """Start writing in_ids / pred_ids at row 0 again (the caller has harvested the previous rows)."""
+        self.step_idx.zero_()
+        self.steps_done = 0
+
     def commit(self, steps=None):
         """Make the cache's host-side lengths reflect `steps` decoded tokens."""
         steps = self.steps_done if steps is None else steps
