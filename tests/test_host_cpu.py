@@ -151,3 +151,32 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_checkpoint_overlay_and_bf16_preference(tmp_path):
+    """checkpoint.py: ema_bf16.safetensors is preferred over ema.safetensors (interactive_vqa_inferencer.py:127-147) and a
+    fine-tuned checkpoint overlays the base one tensor by tensor (eval/vlm/utils.py:71-98); shape mismatches and missing
+    tensors fail loudly."""
+    import pytest
+    import torch
+    from safetensors.torch import save_file
+    from unimedvl_amd.checkpoint import SafetensorsGetter, checkpoint_getter, find_weights_file
+    base, ft = tmp_path / "base", tmp_path / "ft"
+    base.mkdir()
+    ft.mkdir()
+    save_file({"a.weight": torch.ones(2, 3), "b.weight": torch.full((4,), 2.0)}, str(base / "ema.safetensors"))
+    assert find_weights_file(str(base)).endswith("ema.safetensors")
+    save_file({"a.weight": torch.ones(2, 3, dtype=torch.bfloat16) * 3, "b.weight": torch.full((4,), 2.0, dtype=torch.bfloat16)},
+              str(base / "ema_bf16.safetensors"))
+    assert find_weights_file(str(base)).endswith("ema_bf16.safetensors")
+    save_file({"a.weight": torch.full((2, 3), 7.0)}, str(ft / "ema.safetensors"))
+    shapes = {"a.weight": (2, 3), "b.weight": (4,)}
+    get = checkpoint_getter(str(base), shapes, checkpoint_weight_path=str(ft))
+    assert float(get("a.weight")[0, 0]) == 7.0          # fine-tuned tensor wins
+    assert float(get("b.weight")[0]) == 2.0             # missing there -> base
+    with pytest.raises(KeyError):
+        get("c.weight")
+    with pytest.raises(ValueError, match="shape"):
+        SafetensorsGetter(str(base / "ema.safetensors"), {"a.weight": (3, 2)})("a.weight")
+    with pytest.raises(FileNotFoundError):
+        find_weights_file(str(tmp_path / "nothing"))

@@ -43,6 +43,35 @@ class SafetensorsGetter:
         return t
 
 
+class OverlayGetter:
+    """Fine-tuned checkpoint over a base checkpoint: a tensor comes from the first getter that has it.  Replaces the
+    two strict=False load_state_dict passes of the evaluation loader (codes/eval/vlm/utils.py:71-98: base
+    `ema.safetensors` first "to ensure no missing weights", then the fine-tuned `ema(_bf16).safetensors` on top)."""
+
+    def __init__(self, *getters):
+        self.getters = [g for g in getters if g is not None]
+        if not self.getters:
+            raise ValueError("OverlayGetter needs at least one checkpoint")
+
+    def __call__(self, name):
+        err = None
+        for g in self.getters:
+            try:
+                return g(name)
+            except KeyError as e:
+                err = e
+        raise err
+
+
+def checkpoint_getter(model_path, expected_shapes=None, checkpoint_weight_path=None, use_model_checkpoint=False):
+    """get(name) for a checkpoint directory; with `checkpoint_weight_path` the fine-tuned ema(_bf16).safetensors found
+    there overlays the base file of `model_path` (eval/vlm/utils.py:71-98)."""
+    base = SafetensorsGetter(find_weights_file(model_path, use_model_checkpoint), expected_shapes)
+    if checkpoint_weight_path is None:
+        return base
+    return OverlayGetter(SafetensorsGetter(find_weights_file(checkpoint_weight_path, False), expected_shapes), base)
+
+
 def dict_getter(sd):
     return lambda name: sd[name]
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .bagel import Bagel
-from .checkpoint import SafetensorsGetter, find_weights_file, vae_getter
+from .checkpoint import checkpoint_getter, vae_getter
 from .config import UniMedVLConfig
 from .data_utils import add_special_tokens
 from .inferencer import InterleaveInferencer
@@ -65,7 +65,11 @@ class ImageGenerator:
                 raise ValueError("model_path required")
             cfg = UniMedVLConfig.from_checkpoint_dir(model_path, max_latent_size=64, vit_max_num_patch_per_side=70)
             device = f"cuda:{self.config['target_gpu_device']}"
-            get = SafetensorsGetter(find_weights_file(model_path, self.config["use_model_checkpoint"]), all_shapes(cfg))
+            # optional extras over the reference's config keys: "checkpoint_weight_path" overlays a fine-tuned checkpoint on the
+            # base one (eval/vlm/utils.py:71-98); "llm_weight_dtype": "fp8" streams e4m3 LLM weights at decode
+            cfg.llm_weight_dtype = self.config.get("llm_weight_dtype", "bf16")
+            get = checkpoint_getter(model_path, all_shapes(cfg), self.config.get("checkpoint_weight_path"),
+                                    self.config["use_model_checkpoint"])
             model = Bagel(cfg, get, device=device, visual_gen=True, visual_und=True)
             vae_model = AutoEncoder(cfg, vae_getter(os.path.join(model_path, "ae.safetensors")), device=device)
             from .interactive_vqa_inferencer import load_tokenizer

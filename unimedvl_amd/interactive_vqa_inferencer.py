@@ -16,7 +16,7 @@ import torch
 from PIL import Image
 
 from .bagel import Bagel
-from .checkpoint import SafetensorsGetter, find_weights_file
+from .checkpoint import checkpoint_getter
 from .config import UniMedVLConfig
 from .data_utils import add_special_tokens, pil_img2rgb
 from .shapes import all_shapes
@@ -89,7 +89,11 @@ class VQAInferencer:
                 raise ValueError("model_path required")
             cfg = UniMedVLConfig.from_checkpoint_dir(model_path)
             device = f"cuda:{self.config['target_gpu_device']}"
-            get = SafetensorsGetter(find_weights_file(model_path, self.config["use_model_checkpoint"]), all_shapes(cfg))
+            # optional extras over the reference's config keys: "checkpoint_weight_path" overlays a fine-tuned checkpoint on the
+            # base one (eval/vlm/utils.py:71-98); "llm_weight_dtype": "fp8" streams e4m3 LLM weights at decode
+            cfg.llm_weight_dtype = self.config.get("llm_weight_dtype", "bf16")
+            get = checkpoint_getter(model_path, all_shapes(cfg), self.config.get("checkpoint_weight_path"),
+                                    self.config["use_model_checkpoint"])
             model = Bagel(cfg, get, device=device, visual_gen=False, visual_und=True)
             tokenizer = load_tokenizer(model_path)
             tokenizer, new_token_ids, _ = add_special_tokens(tokenizer)
