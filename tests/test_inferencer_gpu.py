@@ -7,6 +7,8 @@ and mean abs diff < 2.0; edit (4*2 = 8x amplification on every step, VAE encode 
 within 6 and mean < 3.0.  The generated image passes through 3-4 guided Euler steps and ~30-60
 bf16 VAE stages; rounding-order noise of that size also separates two CPU formulations of
 the same math (see tests/test_engine_gpu.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -155,3 +157,54 @@ def test_entry_point_classes(stack, tmp_path):
     gen.load_model(model=model, vae_model=vae, tokenizer=tok, new_token_ids=NEW_TOKEN_IDS)
     out = gen.inferencer(text="40 41", image_shapes=(32, 32), num_timesteps=3)
     assert out["image"].size == (32, 32)
+
+
+def test_load_from_checkpoint_directory(tmp_path):
+    """The whole loading path the reference's scripts take (interactive_vqa_inferencer.py:191-268): a checkpoint DIRECTORY
+    with llm_config.json / vit_config.json / ema.safetensors / vocab.json / merges.txt / tokenizer_config.json goes in,
+    VQAInferencer(config).load_model().infer_single(...) comes out - and gives the answer of an engine built in memory from
+    the same tensors.  (Synthetic tiny checkpoint; the tokenizer files are the fixture of tests/golden/tokenizer.)"""
+    import json
+    import shutil
+    from safetensors.torch import save_file
+    from conftest import GOLDEN
+    from oracle.weights import TINY, make_weights
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.data_utils import add_special_tokens
+    from unimedvl_amd.interactive_vqa_inferencer import VQAInferencer
+    from unimedvl_amd.tokenizer import Qwen2Tokenizer
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    c = dict(TINY, vocab=704, vit_side=70, max_latent=64)
+    sd, _ = make_weights(c, seed=77)
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    json.dump(dict(hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                   num_key_value_heads=c["kv_heads"], intermediate_size=c["inter"], vocab_size=c["vocab"], rope_theta=c["rope_theta"],
+                   rms_norm_eps=c["rms_eps"], max_position_embeddings=32768), open(ckpt / "llm_config.json", "w"))
+    json.dump(dict(hidden_size=c["vit_hidden"], num_hidden_layers=c["vit_layers"] + 1, num_attention_heads=c["vit_heads"],
+                   intermediate_size=c["vit_inter"], patch_size=c["patch"]), open(ckpt / "vit_config.json", "w"))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ckpt / "ema.safetensors"))
+    for f in ("vocab.json", "merges.txt", "tokenizer_config.json"):
+        shutil.copy(os.path.join(GOLDEN, "tokenizer", f), ckpt / f)
+
+    rng = np.random.default_rng(3)
+    pil = Image.fromarray(rng.integers(0, 255, (300, 420, 3), dtype=np.uint8))
+    v = VQAInferencer({"model_path": str(ckpt), "max_new_tokens": 6, "do_sample": False})
+    v.load_model()
+    res = v.infer_single(pil, "What abnormality is visible?")
+    assert isinstance(res["answer"], str) and res["image_path"] is None
+
+    tok, nt, _ = add_special_tokens(Qwen2Tokenizer.from_pretrained(str(ckpt)))
+    assert nt == v.new_token_ids and max(nt.values()) < c["vocab"]
+    cfg = UniMedVLConfig.from_dict(c)
+    ref = Bagel(cfg, lambda n: sd[n], device="cuda", visual_gen=False)
+    want = ref.chat(tok, nt, v.image_transform, [pil], "What abnormality is visible?", max_length=6)
+    assert res["answer"] == want
+    # a shape mismatch in the file is reported by tensor name, not as a kernel fault later
+    bad = dict(sd)
+    bad["language_model.model.norm.weight"] = torch.zeros(c["hidden"] + 8, dtype=torch.bfloat16)
+    save_file({k: t.contiguous() for k, t in bad.items()}, str(ckpt / "ema.safetensors"))
+    with pytest.raises(ValueError, match="language_model.model.norm.weight"):
+        VQAInferencer({"model_path": str(ckpt)}).load_model()
