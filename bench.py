@@ -346,6 +346,8 @@ def main():
             + cfg.vit_layers * 4 * (n_tok // B) ** 2 * vh * B + 2 * n_tok * (vh * cfg.hidden + cfg.hidden * cfg.hidden)
         vit = {"images_per_s": round(B / (vit_ms * 1e-3), 1), "ms_per_batch": round(vit_ms, 3), "batch": B,
                "tflops": round(flops / (vit_ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (vit_ms * 1e-3) / 2.5e15, 4),
+               # the other roofline, for completeness (BASELINE.json pairs ViT with HBM): weights once + pixel input + output
+               "hbm_frac_of_8000": round((0.79e9 + n_tok * (3 * cfg.patch ** 2 * 4 + cfg.hidden * 2)) / (vit_ms * 1e-3) / 8e12, 5),
                "note": "ViT tower + connector, 1024 patches/image; MFMA-bound (intensity ~700 flop/B), hd-72 attention included"}
 
     ms_per_step = elapsed * 1e3 / args.steps
@@ -366,7 +368,12 @@ def main():
                      "kernel": ("gemm_skinny8_kernel<1,2,4>" if lw.fp8 else "gemm_skinny_kernel<1,2>") + " (28 gate/up SwiGLU GEMMs + lm_head per step)",
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                     "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                     "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                     # the other roofline, for completeness (BASELINE.json pairs decode with MFMA): at B rows per weight byte
+                     # the MFMA fraction is capped near B / 310 by the HBM roofline
+                     "step_mfma_frac_of_2500": round(B * (2 * lw.decode_weight_bytes() / (1 if lw.fp8 else 2)
+                                                          + 4 * cfg.layers * cfg.heads * cfg.head_dim * ctx)
+                                                     / (ms_per_step * 1e-3) / 2.5e15, 5)},
     }
     if vit is not None:
         out["vit_encode"] = vit
