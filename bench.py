@@ -163,7 +163,16 @@ def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128,
     ts = torch.linspace(1, 0, num_timesteps)
     ts = (3.0 * ts / (1 + 2.0 * ts))[:-1]
     passes = int(sum(3 if (t > 0.4 and t <= 1.0) else 1 for t in ts.tolist()))
+    # MFMA roofline of the leg: flops actually executed by the LLM flow passes (2 packed contexts on guided steps, 1 otherwise;
+    # linear layers 2 x 6.53 G params per token + attention), VAE decode and the small heads left out
+    ntok = (hw // 16) ** 2 + 2
+    lin = 2.0 * cfg.layers * (cfg.hidden * (cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim + cfg.hidden * cfg.hidden + 3 * cfg.hidden * cfg.inter)
+    fl = 0.0
+    for t in ts.tolist():
+        for ctx_len in ([prompt_len + 2, 0] if (t > 0.4 and t <= 1.0) else [prompt_len + 2]):
+            fl += batch * ntok * (lin + 4.0 * cfg.layers * cfg.heads * cfg.head_dim * (ctx_len + ntok))
     return {"images_per_s": round(world * batch / el, 4), "unit": "images/s", "s_per_batch": round(el, 3), "batch_per_gpu": batch,
+            "llm_tflops": round(fl / el / 1e12, 1), "mfma_frac_of_2500": round(fl / el / 2.5e15, 4),
             "image": f"{hw}x{hw}", "num_timesteps": num_timesteps, "llm_passes_per_image": passes, "prompt_tokens": prompt_len,
             "note": "reference schedule = 131 sequential passes/image; here the guided passes of a step run as one packed "
                     "forward and the no-image pass (bit-identical context for pure T2I) reuses v_t: same arithmetic, 90 pass-equivalents",

@@ -288,6 +288,9 @@ class Bagel(BagelPrep):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0
         if key_values_lens is not None and [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
             raise ValueError("key_values_lens disagree with the cache")
+        if max_length <= 0:   # nothing to decode (the reference would fail on torch.stack([]) here, bagel.py:1316)
+            out = torch.zeros((0, len(past_key_values.lens)), dtype=torch.int64, device=self.device)
+            return (out, torch.zeros((0, len(past_key_values.lens), self.cfg.vocab), dtype=BF16, device=self.device)) if return_logits else out
         sess = DecodeSession(self.language_model, past_key_values, packed_start_tokens, packed_query_position_ids,
                              max_length, use_graph=self.decode_use_graph and not return_logits,
                              do_sample=do_sample, temperature=temperature, seed=seed)
