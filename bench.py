@@ -222,8 +222,11 @@ def main():
         cfg = UniMedVLConfig()
         img_hw, prompt_len = 448, 32
     else:
-        from oracle.weights import TINY
-        cfg = UniMedVLConfig.from_dict(TINY)
+        # small dims for a quick functional run of this script (same numbers as the parity tests' tiny model; spelled out
+        # here so that only the cpu_baseline leg touches oracle/)
+        cfg = UniMedVLConfig.from_dict(dict(
+            hidden=256, layers=2, heads=2, kv_heads=1, inter=384, vocab=320, vit_hidden=144, vit_layers=2, vit_heads=2,
+            vit_inter=208, patch=14, vit_side=8, max_latent=8, vae_ch=32, vae_mult=(1, 2, 4, 4), vae_res=1, z_channels=16))
         img_hw, prompt_len = 56, 8
     cfg.llm_weight_dtype = args.weights
     B = args.batch

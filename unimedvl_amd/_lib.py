@@ -11,8 +11,6 @@ LIB_PATH = os.path.join(HERE, "lib", "libunimedvl_hip.so")
 
 EPI_BIAS, EPI_GELU_TANH, EPI_SILU, EPI_RESIDUAL, EPI_SWIGLU, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32
 
-c_u16p = C.c_void_p  # device pointers travel as integers
-
 
 class GemmArgs(C.Structure):
     _fields_ = [
@@ -50,16 +48,6 @@ class AttnArgs(C.Structure):
         ("v_head_stride", C.c_int64), ("v_d_stride", C.c_int64),
         ("nseg", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("causal", C.c_int),
         ("max_q", C.c_int), ("max_kv", C.c_int), ("nsplit", C.c_int), ("workspace", C.c_void_p),
-    ]
-
-
-class ConvArgs(C.Structure):
-    _fields_ = [
-        ("x", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
-        ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p),
-        ("B", C.c_int), ("Cin", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cout", C.c_int),
-        ("Hout", C.c_int), ("Wout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
-        ("upsample", C.c_int), ("swish", C.c_int),
     ]
 
 
