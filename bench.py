@@ -407,7 +407,7 @@ def main():
         torch.cuda.empty_cache()
         cfg8 = UniMedVLConfig.from_dict(cfg.to_dict())
         cfg8.llm_weight_dtype = "fp8"
-        model8 = Bagel(cfg8, random_getter(cfg8, dev, seed=1234), device=dev, visual_gen=False, visual_und=True)
+        model8 = Bagel(cfg8, random_getter(cfg8, dev, seed=1234), device=dev, visual_gen=want_t2i, visual_und=True)
         l8 = decode_leg(model8)
         w8 = model8.language_model.w
         ms8 = l8["elapsed"] * 1e3 / args.steps
@@ -421,6 +421,11 @@ def main():
             "workload": "configs[4]-style: same batch / context as the headline run, fp8 weights",
             "parity": "umv_gemm_fp8w == umv_gemm_bf16 on the dequantised weights bit for bit; engine vs the CPU oracle on the "
                       "dequantised weights at the bf16 tolerances (tests/test_fp8_gpu.py); split-K decode mode on"}
+        if want_t2i:   # the T2I half of configs[4]'s mixed batch on the same fp8-weight model: flow passes run the bf16 image of
+            # the dequantised weights on the MFMA path (M > 64), so this matches the bf16 T2I rate by construction
+            l8["sess"] = l8["cache"] = None
+            t8 = run_t2i(model8, cfg8, dev, rank, world, dist, num_timesteps=args.t2i_steps)
+            out["decode_fp8_weights"]["t2i_images_per_s_same_model"] = t8["images_per_s"]
         del model8, l8
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
