@@ -216,6 +216,29 @@ typedef struct {
 size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit);
 int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);
 
+/* One decode step's attention with umv_qkv_post folded in (one query token per segment, hd = 128, `und` chain): the wave
+ * of a (segment, kv head, key split) normalises + rotates its G query heads and the new key straight from the raw fused QKV
+ * row (qwen2_navit.py:544-583), appends K / V^T at slot kv_len-1 (:585-600) and attends over kv_len keys (:605-614); splits
+ * are merged as in umv_attn_varlen.  Same MFMAs on the same operands as qkv_post + attn_varlen; only the row sum of squares
+ * of the q/k norms is accumulated in another order. */
+typedef struct {
+    const uint16_t* qkv;   /* [nseg, (nq + 2 nkv) * hd] raw QKV GEMM output (bias applied), row stride ld_qkv */
+    int64_t ld_qkv;
+    uint16_t* out;         /* [nseg, nq, hd] */
+    const int32_t* cu_q;   /* [nseg + 1] = 0..nseg (one token per segment; used by the split merge) */
+    const int32_t* kv_len; /* [nseg] keys per segment INCLUDING this step's token */
+    const int32_t* tok_pos;/* [nseg] rope position of this step's token */
+    const uint16_t* q_norm_w; const uint16_t* k_norm_w; /* [hd] */
+    const uint16_t* cos_tab; const uint16_t* sin_tab;   /* [max_pos, hd] bf16 */
+    uint16_t* k_slab; uint16_t* vt_slab;
+    int64_t k_seg_stride, k_head_stride, v_seg_stride, v_head_stride, v_d_stride;
+    int nseg, nq, nkv, hd;
+    float eps;
+    int nsplit;
+    void* workspace;       /* umv_attn_workspace_bytes(nseg, nq, hd, 1, nsplit) when nsplit > 1 */
+} umv_attn_decode_args;
+int umv_attn_decode_fused(const umv_attn_decode_args* a, umv_stream_t stream);
+
 /* decode bookkeeping kept on device so a whole step replays from a hipGraph:
  * slot[b]+=1, pos[b]+=1, kv_len[b]+=1 (the .tolist() bookkeeping of bagel.py:1266-1275,1303-1310) */
 int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int B, umv_stream_t stream);

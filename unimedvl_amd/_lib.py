@@ -51,7 +51,20 @@ class AttnArgs(C.Structure):
     ]
 
 
+class AttnDecodeArgs(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("ld_qkv", C.c_int64), ("out", C.c_void_p), ("cu_q", C.c_void_p), ("kv_len", C.c_void_p),
+        ("tok_pos", C.c_void_p), ("q_norm_w", C.c_void_p), ("k_norm_w", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
+        ("k_slab", C.c_void_p), ("vt_slab", C.c_void_p),
+        ("k_seg_stride", C.c_int64), ("k_head_stride", C.c_int64), ("v_seg_stride", C.c_int64),
+        ("v_head_stride", C.c_int64), ("v_d_stride", C.c_int64),
+        ("nseg", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("eps", C.c_float), ("nsplit", C.c_int),
+        ("workspace", C.c_void_p),
+    ]
+
+
 _SIGS = {
+    "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
     "umv_version": (C.c_int, []),
     "umv_last_error": (C.c_char_p, []),
     "umv_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int]),

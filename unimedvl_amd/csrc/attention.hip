@@ -17,6 +17,8 @@
 // attention_prefill.hip: the nsplit == 1 path with K / V^T shared through LDS (bit-identical results)
 bool umv_attn_prefill_enabled();
 int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s);
+int umv_attn_combine_launch(const float* ws, uint16_t* out, const int32_t* cu_q, int nseg, int nq, int hd, int nsplit, int64_t rows,
+                            hipStream_t s);
 
 __device__ __forceinline__ bf16x8 mask_keys(bf16x8 v, int nvalid) {
     // keep the first nvalid (0..8) bf16 elements, zero the rest
@@ -287,16 +289,19 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     else
         UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "attn: head_dim %d unsupported (128, 72, 512)", a.hd);
     UMV_LAUNCH_CHECK();
-    if (a.nsplit > 1) {
-        // grid over the static bound nseg*max_q tokens; rows beyond cu_q[nseg]*nq exit on device
-        int64_t rows = (int64_t)a.nseg * a.max_q * a.nq;
-        if (a.hd == 128)
-            hipLaunchKernelGGL((attn_combine_kernel<128, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
-                               (const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.nsplit);
-        else
-            hipLaunchKernelGGL((attn_combine_kernel<72, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
-                               (const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.nsplit);
-        UMV_LAUNCH_CHECK();
-    }
+    if (a.nsplit > 1)   // grid over the static bound nseg*max_q tokens; rows beyond cu_q[nseg]*nq exit on device
+        return umv_attn_combine_launch((const float*)a.workspace, a.out, a.cu_q, a.nseg, a.nq, a.hd, a.nsplit,
+                                       (int64_t)a.nseg * a.max_q * a.nq, s);
+    return UMV_OK;
+}
+
+// shared with attention_decode.hip
+int umv_attn_combine_launch(const float* ws, uint16_t* out, const int32_t* cu_q, int nseg, int nq, int hd, int nsplit, int64_t rows,
+                            hipStream_t s) {
+    if (hd == 128)
+        hipLaunchKernelGGL((attn_combine_kernel<128, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, out, cu_q, nseg, nq, nsplit);
+    else
+        hipLaunchKernelGGL((attn_combine_kernel<72, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, out, cu_q, nseg, nq, nsplit);
+    UMV_LAUNCH_CHECK();
     return UMV_OK;
 }

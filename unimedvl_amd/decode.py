@@ -39,6 +39,9 @@ class DecodeSession:
         self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)
         max_kv = max(cache.lens) + max_length + 1
         # split the key range so that every wavefront walks ~2 blocks of 32 keys (latency bound otherwise)
+        import os as _os
+        if nsplit is None and _os.environ.get("UMV_DECODE_NSPLIT"):
+            nsplit = int(_os.environ["UMV_DECODE_NSPLIT"])   # tuning only
         self.nsplit = nsplit if nsplit is not None else max(1, min(32, (max_kv + 63) // 64))
         self.ws = ops.attn_workspace(B, nq, hd, 1, self.nsplit, dev) if self.nsplit > 1 else None
         self.max_kv = max_kv
@@ -92,6 +95,7 @@ class DecodeSession:
                 assert len(self.sk) == 3 and all(1 < v <= 64 for v in self.sk)
                 self.p_qkv = torch.empty((self.sk[0], B, (nq + 2 * nkv) * hd), dtype=torch.float32, device=dev)
                 self.p_h = torch.empty((max(self.sk[1], self.sk[2]), B, H), dtype=torch.float32, device=dev)
+        self.fuse_attn = os.environ.get("UMV_DECODE_FUSE_ATTN", "1") not in ("0", "") and hd == 128 and self.sk is None
         self.do_sample, self.temperature, self.seed = bool(do_sample), float(temperature), int(seed)
         self.steps_done = 0
         self.graph = None
@@ -168,10 +172,14 @@ class DecodeSession:
                 ops.gemm(self.x, qkv_w, out=self.qkv)
             # window 2 (RoPE/KV append, attention, combine): o_proj weights and the head of gate/up
             self._prefetch([(o_w.wp, 0, None), (lw.gate_up.wp, 0, self.pf_w2 * MB)])
-            ops.qkv_post(self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
-                         cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin)
-            ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
-                          self.nsplit, self.ws)
+            if self.fuse_attn:   # q/k norm + RoPE + KV append inside the attention kernel: one launch less per layer
+                ops.attn_decode_fused(self.qkv, self.o, c.slabs[l], self.cu_q, self.kv_len, self.tok_pos, nq, nkv, hd,
+                                      cfg.rms_eps, lw.q_norm, lw.k_norm, w.cos, w.sin, self.nsplit, self.ws)
+            else:
+                ops.qkv_post(self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
+                             cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin)
+                ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
+                              self.nsplit, self.ws)
             self._join()
             ops.gemm(self.o, o_w, out=self.seq, residual=self.seq)
             if self.fuse_norm:

@@ -395,6 +395,20 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
     return out
 
 
+def attn_decode_fused(qkv, out, slab, cu_q, kv_len, tok_pos, nq, nkv, hd, eps, q_norm, k_norm, cos_tab, sin_tab, nsplit=1,
+                      workspace=None):
+    """One decode step: q/k norm + RoPE + KV append + attention over kv_len keys, from the raw fused QKV rows."""
+    lib = _lib.load()
+    _req(qkv, BF16, "qkv")
+    a = _lib.AttnDecodeArgs(
+        qkv=qkv.data_ptr(), ld_qkv=qkv.stride(0), out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
+        tok_pos=tok_pos.data_ptr(), q_norm_w=q_norm.data_ptr(), k_norm_w=k_norm.data_ptr(), cos_tab=cos_tab.data_ptr(),
+        sin_tab=sin_tab.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
+        eps=eps, nsplit=nsplit, workspace=None if workspace is None else workspace.data_ptr(), **slab.strides())
+    check(lib.umv_attn_decode_fused(C.byref(a), _stream()), "umv_attn_decode_fused")
+    return out
+
+
 def decode_advance(tok_slot, tok_pos, kv_len):
     lib = _lib.load()
     check(lib.umv_decode_advance(_p(tok_slot), _p(tok_pos), _p(kv_len), tok_slot.numel(), _stream()), "umv_decode_advance")
