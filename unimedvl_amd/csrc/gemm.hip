@@ -920,8 +920,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // split-K decode GEMM: 4 n-tiles per workgroup share every x fragment (x re-reads from L2 drop 4x against the
         // one-tile workgroups), the K range is cut k_splits ways to keep >= 256 workgroups, partial sums go to fp32
         if (a.M <= 16) return launch_skinny<1, 4, 2, true, 0>(a, KT, NTT, s);
-        if (a.M <= 32) return launch_skinny<2, 4, 2, false, 0>(a, KT, NTT, s);
-        return launch_skinny<4, 4, 1, false, 0>(a, KT, NTT, s);
+        if (a.M <= 32) return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
+        return launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
     }
     if (a.M <= 64 && (a.M <= skinny_max || TH != 16)) {
         const bool two = (a.epilogue & UMV_EPI_SWIGLU) || NTT >= 1024;
@@ -933,8 +933,9 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // M > 16: every workgroup re-reads all of x from L2, so wide-N GEMMs take 4 n-tiles per workgroup (x : weight bytes
         // = M : 64); UMV_GEMM_SKINNY_NT=2 restores the 2-tile kernels (tuning only)
         static int nt4 = -1;
-        if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : 1; }
-        if (two && nt4 && TH == 16) return a.M <= 32 ? launch_skinny<2, 4, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 4, 1, false, 0>(a, KT, NTT, s);
+        if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : (e && atoi(e) == 8) ? 8 : 1; }
+        if (two && nt4 == 8 && TH == 16 && a.M <= 32) return launch_skinny<2, 8, 1, true, 0>(a, KT, NTT, s);
+        if (two && nt4 && TH == 16) return a.M <= 32 ? launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s) : launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
