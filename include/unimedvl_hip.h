@@ -104,6 +104,35 @@ int umv_quantize_pack_weight_fp8(const uint16_t* w, const uint16_t* w_up, uint8_
 /* M <= 64 only; a->wp = the e4m3 image, a->w_scale = its scales; norm_w / tile_rows unsupported */
 int umv_gemm_fp8w(const umv_gemm_args* a, umv_stream_t stream);
 
+/* W8A8 on the fp8 matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4) for the MFMA-bound GEMMs of the fp8 mode
+ * (M > 64: prefill, flow passes).  Activations are quantised per ROW the way weights are per channel:
+ *   sx[m] = smallest 2^e with 448 * 2^e >= max_k |x[m,k]|,  xq = rne_e4m3(x / sx)   (umv_quantize_act_fp8; rows may be
+ *   gathered through row_idx; xq is [M, ldq] row-major, zero padded to ldq, a multiple of 128)
+ *   out[m,n] = epilogue(sx[m] * sw[n] * sum_k xq[m,k] * wq[n,k])                    (umv_gemm_fp8a8w, fp32 accumulate)
+ * Every product and both scales are exact, so the result equals a linear on the dequantised operands up to the order
+ * of the fp32 sums - that is how oracle/fp8.py restates it.  The weight image for this instruction is a re-tiling of the
+ * e4m3 image: P8M[n/16][k/128][(k%32)/16][lane = ((k%128)/32)*16 + n%16][k%16]. */
+size_t umv_packed_weight_fp8_mfma_bytes(int N, int K);
+int umv_repack_weight_fp8_mfma(const uint8_t* packed8, uint8_t* out, int N, int K, umv_stream_t stream);
+int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_t* row_idx, uint8_t* xq, int64_t ldq, float* x_scale, int M,
+                         int K, umv_stream_t stream);
+typedef struct {
+    const uint8_t* xq;        /* [M, ldq] e4m3, rows 0..M-1 (already gathered) */
+    int64_t ldq;
+    const float* x_scale;     /* [M] */
+    const uint8_t* wp;        /* umv_repack_weight_fp8_mfma image */
+    const float* w_scale;     /* scales of umv_quantize_pack_weight_fp8 (image row order) */
+    const uint16_t* bias;
+    const uint16_t* residual;
+    int64_t ldr;
+    void* out;                /* bf16 [*, ldo] */
+    int64_t ldo;
+    const int32_t* row_idx;   /* optional [M]: residual / out rows (MoT routing); xq / x_scale are indexed by m */
+    int M, N, K;
+    int epilogue;             /* UMV_EPI_* except OUT_F32 */
+} umv_gemm8_args;
+int umv_gemm_fp8a8w(const umv_gemm8_args* a, umv_stream_t stream);
+
 /* ------------------------------------------------------------------ decode GEMM (M <= 16; Bagel.generate_text,
  * bagel.py:1262-1314 -> the F.linear calls of one-token-per-sample steps: qwen2_navit.py:541-543,617-620,
  * modeling_qwen2.py:234-235, bagel.py:1295).  One persistent workgroup per CU streams ONE contiguous slab of a

@@ -39,6 +39,18 @@ def quantize_rows(w: torch.Tensor):
     return q.view(torch.uint8), scale, deq
 
 
+def quantize_act_rows(x: torch.Tensor):
+    """W8A8 mode (umv_quantize_act_fp8): activations get the weights' treatment per ROW.  Same arithmetic as quantize_rows."""
+    return quantize_rows(x)
+
+
+def w8a8_linear(x: torch.Tensor, w_deq: torch.Tensor, b=None) -> torch.Tensor:
+    """What umv_gemm_fp8a8w computes, restated: a bf16 linear (fp32 accumulate, one rounding of the sum [+ bias]) on the
+    per-row-dequantised activations and the per-channel-dequantised weights - both exactly representable in bf16."""
+    xd = quantize_act_rows(x)[2]
+    return torch.nn.functional.linear(xd, w_deq.to(torch.bfloat16), None if b is None else b.to(torch.bfloat16))
+
+
 def unpack_image(img: torch.Tensor, N: int, K: int, swiglu_I: int = 0) -> torch.Tensor:
     """Invert the P8[nt][kt8][lane][16] image of umv_quantize_pack_weight_fp8 -> uint8 [rows, K]
     (rows = N, or [2, I, K] stacked gate/up when swiglu_I > 0)."""

@@ -11,13 +11,19 @@ import torch  # noqa: E402
 from unimedvl_amd import ops  # noqa: E402
 
 
+FP8 = "--fp8" in sys.argv   # W8A8 on the fp8 matrix instruction (the time includes the per-row activation quantisation)
+
+
 def bench(M, N, K, swiglu=False, reps=20):
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     if swiglu:
-        lin = ops.PackedLinear.from_gate_up(torch.randn(N // 2, K, device="cuda").to(torch.bfloat16) * 0.02,
-                                            torch.randn(N // 2, K, device="cuda").to(torch.bfloat16) * 0.02)
+        mk = ops.PackedLinear.from_gate_up_fp8 if FP8 else ops.PackedLinear.from_gate_up
+        lin = mk(torch.randn(N // 2, K, device="cuda").to(torch.bfloat16) * 0.02, torch.randn(N // 2, K, device="cuda").to(torch.bfloat16) * 0.02)
     else:
-        lin = ops.PackedLinear.from_weight(torch.randn(N, K, device="cuda").to(torch.bfloat16) * 0.02)
+        mk = ops.PackedLinear.from_weight_fp8 if FP8 else ops.PackedLinear.from_weight
+        lin = mk(torch.randn(N, K, device="cuda").to(torch.bfloat16) * 0.02)
+    if FP8:
+        lin.enable_fp8_mfma()
     out = torch.empty(M, N // 2 if swiglu else N, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
         ops.gemm(x, lin, out=out)

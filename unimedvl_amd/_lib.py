@@ -63,7 +63,20 @@ class AttnDecodeArgs(C.Structure):
     ]
 
 
+class Gemm8Args(C.Structure):
+    _fields_ = [
+        ("xq", C.c_void_p), ("ldq", C.c_int64), ("x_scale", C.c_void_p), ("wp", C.c_void_p), ("w_scale", C.c_void_p),
+        ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("row_idx", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
+    ]
+
+
 _SIGS = {
+    "umv_packed_weight_fp8_mfma_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "umv_repack_weight_fp8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "umv_quantize_act_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "umv_gemm_fp8a8w": (C.c_int, [C.POINTER(Gemm8Args), C.c_void_p]),
     "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
     "umv_version": (C.c_int, []),
     "umv_last_error": (C.c_char_p, []),

@@ -1,0 +1,274 @@
+// W8A8 GEMM on the gfx950 block-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, scales fixed at 2^0):
+// the MFMA-bound half of the fp8 mode (BASELINE.json configs[4]) - prefill and flow passes, M > 64 rows.
+//
+//   out[m,n] = epi( sx[m] * sw[n] * sum_k xq[m,k] * wq[n,k] )        xq, wq: OCP e4m3;  sx, sw: powers of two
+//
+// wq / sw are the per-channel quantised weights of umv_quantize_pack_weight_fp8; xq / sx come from
+// umv_quantize_act_fp8 (per ROW: sx[m] = smallest 2^e with 448 * 2^e >= max_k |x[m,k]|).  Products of two e4m3 values are
+// exact in fp32, the scales are exact, so the only rounding is the fp32 accumulation: the CPU oracle restates this as a
+// bf16 linear on the dequantised operands (oracle/fp8.py).  No reference counterpart exists (the reference is bf16).
+//
+// Operand layout (checked by tools/fp8_mfma_probe.hip): lane (r = l & 15, g = l >> 4) of the A / B operand holds 32
+// consecutive k (g*32 .. g*32+31) of row r, 32 bytes; D as every 16x16 MFMA (col = l & 15, row = g*4 + reg).
+//   weight image P8M[n/16][k/128][h][lane][16 B]: plane h holds bytes h*16 .. h*16+15 of every lane's 32 - two 1 KiB planes
+//   per (16 x 128) tile, each a straight LDS-DMA copy; x planes are gathered per lane from row-major xq[M][ldq].
+// Pipeline: the LDS-DMA / counted-wait / one-barrier-per-k-step scheme of gemm_tiled_kernel with k-steps of 128.
+#include "common.h"
+#include "../../include/unimedvl_hip.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((address_space(3))) void* lds8_ptr_t;
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_page8[4] = {0, 0, 0, 0};
+
+// ----------------------------------------------------------------------------- weight image for the MFMA
+// from the decode image P8[nt][k/64][lane = g*16 + r][16 B: (k%64)/32 * 8 + k%8]; one thread per 8-byte piece
+__global__ void repack_fp8_mfma_kernel(const uint8_t* __restrict__ p8, uint8_t* __restrict__ out, int KT8, int KT128, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // ((nt*KT128 + kt)*2 + h)*64 + lane)*2 + half
+    if (gid >= total) return;
+    const int half = (int)(gid & 1);
+    const int lane = (int)((gid >> 1) & 63);
+    const int h = (int)((gid >> 7) & 1);
+    const int64_t tile = gid >> 8;
+    const int kt = (int)(tile % KT128);
+    const int64_t nt = tile / KT128;
+    const int r = lane & 15, g = lane >> 4;
+    const int k0 = kt * 128 + g * 32 + h * 16 + half * 8;
+    const int kt8 = k0 >> 6, rem = k0 & 63;
+    u32x2 v = {0u, 0u};
+    if (kt8 < KT8) v = *reinterpret_cast<const u32x2*>(p8 + ((nt * KT8 + kt8) * 64 + ((rem & 31) >> 3) * 16 + r) * 16 + (rem >> 5) * 8);
+    *reinterpret_cast<u32x2*>(out + gid * 8) = v;
+}
+
+extern "C" size_t umv_packed_weight_fp8_mfma_bytes(int N, int K) {
+    return ((size_t)(N + 15) / 16) * ((size_t)(K + 127) / 128) * 2048;
+}
+
+extern "C" int umv_repack_weight_fp8_mfma(const uint8_t* packed8, uint8_t* out, int N, int K, umv_stream_t stream) {
+    UMV_CHECK(packed8 && out && N > 0 && K > 0, UMV_ERR_ARG, "repack_weight_fp8_mfma: bad args");
+    const int KT8 = (K + 63) / 64, KT128 = (K + 127) / 128;
+    const int64_t total = (int64_t)((N + 15) / 16) * KT128 * 2 * 64 * 2;
+    hipLaunchKernelGGL(repack_fp8_mfma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed8, out,
+                       KT8, KT128, total);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- activations: per-row e4m3
+__device__ __forceinline__ float act_pow2_scale(float amax) {   // smallest 2^e with 448 * 2^e >= amax (1 for a zero row)
+    if (!(amax > 0.f)) return 1.0f;
+    int ea;
+    const float ma = frexpf(amax, &ea);
+    return ldexpf(1.0f, ma <= 0.875f ? ea - 9 : ea - 8);
+}
+
+__global__ __launch_bounds__(256) void quantize_act_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, const int32_t* __restrict__ row_idx,
+                                                               uint8_t* __restrict__ xq, int64_t ldq, float* __restrict__ xs, int K) {
+    __shared__ float part[4];
+    const int m = blockIdx.x;
+    const bf16_t* xr = x + (row_idx ? (int64_t)row_idx[m] : (int64_t)m) * ldx;
+    const int nv = K / 8;
+    float mx = 0.f;
+    for (int c = threadIdx.x; c < nv; c += 256) {
+        const bf16x8 v = ldg_frag(xr + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(bf2f((bf16_t)v[j])));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float s = act_pow2_scale(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+    if (threadIdx.x == 0) xs[m] = s;
+    const float inv = 1.0f / s;
+    uint8_t* q = xq + (int64_t)m * ldq;
+    for (int c = threadIdx.x; c < (int)(ldq / 8); c += 256) {
+        int lo = 0, hi = 0;
+        if (c < nv) {
+            const bf16x8 v = ldg_frag(xr + c * 8);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = bf2f((bf16_t)v[j]) * inv;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        }
+        u32x2 o = {(uint32_t)lo, (uint32_t)hi};
+        *reinterpret_cast<u32x2*>(q + c * 8) = o;   // zero padded up to ldq
+    }
+}
+
+extern "C" int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_t* row_idx, uint8_t* xq, int64_t ldq, float* x_scale,
+                                    int M, int K, umv_stream_t stream) {
+    UMV_CHECK(x && xq && x_scale && M >= 0 && K > 0, UMV_ERR_ARG, "quantize_act_fp8: bad args");
+    UMV_CHECK((K % 8) == 0 && (ldx % 8) == 0 && (ldq % 128) == 0 && ldq >= K, UMV_ERR_ARG,
+              "quantize_act_fp8: K (%d), ldx must be multiples of 8 and ldq (%lld) a multiple of 128 >= K", K, (long long)ldq);
+    if (M == 0) return UMV_OK;
+    hipLaunchKernelGGL(quantize_act_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, row_idx, xq, ldq, x_scale, K);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// ----------------------------------------------------------------------------- the GEMM
+template <int WN, int WM, int TN, int TM, int NBUF>
+__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_args a, int KT, int NTT, int mblocks, int nblocks) {
+    constexpr int NW = WN * WM;
+    constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+    constexpr int WPL = 2 * (BN / 16), XPL = 2 * (BM / 16);   // 1 KiB planes per k-step: W then x
+    constexpr int TPW = (WPL + XPL) / NW;
+    static_assert((WPL + XPL) % NW == 0, "staging planes must divide evenly over the waves");
+    constexpr int BUF = (WPL + XPL) * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wn = wave % WN, wm = wave / WN;
+    const int nwg = mblocks * nblocks;
+    int bid = blockIdx.x;
+    {   // XCD-aware order, as gemm_tiled_kernel
+        const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int mblk = bid % mblocks, nblk = bid / mblocks;
+    const int m0 = mblk * BM;
+    const int nt_blk = nblk * (BN / 16);
+    const int nt_base = nt_blk + wn * TN;
+
+    const uint8_t* src[TPW];
+    bool tvalid[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int f = wave * TPW + i;
+        if (f < WPL) {
+            const int nt = nt_blk + (f >> 1), h = f & 1;
+            tvalid[i] = nt < NTT;
+            src[i] = a.wp + (((int64_t)(tvalid[i] ? nt : 0) * KT) * 2 + h) * 1024 + lane * 16;     // + kt * 2048 per step
+        } else {
+            const int fx = f - WPL;
+            const int m = m0 + (fx >> 1) * 16 + r, h = fx & 1;
+            tvalid[i] = m < a.M;
+            src[i] = a.xq + (int64_t)(tvalid[i] ? m : 0) * a.ldq + g * 32 + h * 16;                 // + kt * 128 per step
+        }
+    }
+    const uint8_t* zero = reinterpret_cast<const uint8_t*>(g_zero_page8);
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int f = wave * TPW + i;
+            const uint8_t* p = tvalid[i] ? src[i] + (int64_t)kt * (f < WPL ? 2048 : 128) : zero;
+            __builtin_amdgcn_global_load_lds((const void*)p, (lds8_ptr_t)(smem + buf * BUF + f * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p)
+        if (p < KT) stage(p, p);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int ahead = min(NBUF - 2, KT - 1 - kt);   // k-steps still allowed in flight behind step kt
+        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NBUF - 1 < KT) stage(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
+        const char* wb = smem + (kt % NBUF) * BUF + lane * 16;
+        const char* xb = wb + WPL * 1024;
+        i32x8 xf[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(xb + (2 * (wm * TM + j)) * 1024);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(xb + (2 * (wm * TM + j) + 1) * 1024);
+            xf[j] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(wb + (2 * (wn * TN + t)) * 1024);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(wb + (2 * (wn * TN + t) + 1) * 1024);
+            const i32x8 wf = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[t][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[t][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    }
+    // epilogue: exact power-of-two scales, then the shared bf16 epilogue (bias / activation / SwiGLU / residual)
+    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    const bool swiglu = (a.epilogue & UMV_EPI_SWIGLU) != 0;
+    static_for<0, TM>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const int m = m0 + (wm * TM + j) * 16 + r;
+        if (m < a.M) {
+            const int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
+            const float sx = a.x_scale[m];
+            if (swiglu) {
+                static_for<0, TN / 2>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    const int ntile = nt_base + 2 * p;
+                    if (ntile < NTT) {
+                        const int c0 = (ntile >> 1) * 16 + g * 4;
+                        const f32x4 sg = *reinterpret_cast<const f32x4*>(a.w_scale + ntile * 16 + g * 4);
+                        const f32x4 su = *reinterpret_cast<const f32x4*>(a.w_scale + (ntile + 1) * 16 + g * 4);
+                        float gg[4] = {acc[2 * p][j].x * sg.x * sx, acc[2 * p][j].y * sg.y * sx, acc[2 * p][j].z * sg.z * sx, acc[2 * p][j].w * sg.w * sx};
+                        float uu[4] = {acc[2 * p + 1][j].x * su.x * sx, acc[2 * p + 1][j].y * su.y * sx, acc[2 * p + 1][j].z * su.z * sx,
+                                       acc[2 * p + 1][j].w * su.w * sx};
+                        epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
+                    }
+                });
+            } else {
+                static_for<0, TN>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const int n0 = (nt_base + t) * 16 + g * 4;
+                    if (n0 < a.N) {
+                        const f32x4 sw = *reinterpret_cast<const f32x4*>(a.w_scale + n0);
+                        epi_store4(e, orow, n0, acc[t][j].x * sw.x * sx, acc[t][j].y * sw.y * sx, acc[t][j].z * sw.z * sx, acc[t][j].w * sw.w * sx);
+                    }
+                });
+            }
+        }
+    });
+}
+
+template <int WN, int WM, int TN, int TM, int NBUF>
+static int launch_tiled8(const umv_gemm8_args& a, int KT, int NTT, hipStream_t s) {
+    constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+    constexpr size_t lds = (size_t)NBUF * 2 * (BN / 16 + BM / 16) * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled8_kernel<WN, WM, TN, TM, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    const int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_tiled8_kernel<WN, WM, TN, TM, NBUF>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks,
+                       nblocks);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+extern "C" int umv_gemm_fp8a8w(const umv_gemm8_args* ap, umv_stream_t stream) {
+    UMV_CHECK(ap != nullptr, UMV_ERR_ARG, "gemm_fp8a8w: null args");
+    const umv_gemm8_args a = *ap;
+    UMV_CHECK(a.xq && a.x_scale && a.wp && a.w_scale && a.out, UMV_ERR_ARG, "gemm_fp8a8w: null pointer");
+    UMV_CHECK(a.M >= 0 && a.N > 0 && a.K > 0 && (a.ldq % 128) == 0 && a.ldq >= a.K, UMV_ERR_ARG,
+              "gemm_fp8a8w: bad shape M=%d N=%d K=%d ldq=%lld (ldq: multiple of 128, >= K)", a.M, a.N, a.K, (long long)a.ldq);
+    UMV_CHECK(!(a.epilogue & UMV_EPI_BIAS) || a.bias, UMV_ERR_ARG, "gemm_fp8a8w: BIAS without bias pointer");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_RESIDUAL) || a.residual, UMV_ERR_ARG, "gemm_fp8a8w: RESIDUAL without residual pointer");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm_fp8a8w: SWIGLU needs N %% 32 == 0");
+    UMV_CHECK(!(a.epilogue & UMV_EPI_OUT_F32), UMV_ERR_UNSUPPORTED, "gemm_fp8a8w: OUT_F32 unsupported");
+    if (a.M == 0) return UMV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int KT = (a.K + 127) / 128, NTT = (a.N + 15) / 16;
+    static int force = -1;   // tuning only: UMV_GEMM8_TILE=<256|258|128>
+    if (force < 0) { const char* e = getenv("UMV_GEMM8_TILE"); force = e ? atoi(e) : 0; }
+    const long wg256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    int cfg = wg256 >= 160 ? 256 : 258;
+    if (force) cfg = force;
+    if (cfg == 256) return launch_tiled8<2, 4, 8, 4, 2>(a, KT, NTT, s);   // 256 x 256 x 128, 2 buffers of 64 KiB
+    if (cfg == 128) return launch_tiled8<2, 2, 4, 4, 2>(a, KT, NTT, s);   // 128 x 128 x 128, 2 buffers of 32 KiB
+    return launch_tiled8<4, 2, 4, 4, 2>(a, KT, NTT, s);                   // 256(n) x 128(m) x 128, 2 buffers of 48 KiB
+}

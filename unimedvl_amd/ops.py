@@ -31,13 +31,27 @@ def _req(t, dtype, name):
 class PackedLinear:
     """nn.Linear weight [N,K] (+bias) re-tiled for the MFMA GEMM kernels."""
 
-    __slots__ = ("wp", "bias", "N", "K", "swiglu", "th", "w8", "scale")
+    __slots__ = ("wp", "bias", "N", "K", "swiglu", "th", "w8", "scale", "w8m")
 
     def __init__(self, wp, bias, N, K, swiglu=False, th=16, w8=None, scale=None):
         self.wp, self.bias, self.N, self.K, self.swiglu, self.th = wp, bias, N, K, swiglu, th
         # fp8 weights (BASELINE.json configs[4]): w8 = e4m3 image streamed by the decode GEMM (M <= 64), scale = its
         # power-of-two channel scales; wp is then the bf16 image of the SAME dequantised weights for M > 64
         self.w8, self.scale = w8, scale
+        # optional: the e4m3 image re-tiled for the fp8 matrix instruction; when present, GEMMs with M > 64 rows quantise
+        # their activations per row and run W8A8 (enable_fp8_mfma)
+        self.w8m = None
+
+    def enable_fp8_mfma(self, keep_bf16=False):
+        """Build the fp8-MFMA image from the e4m3 image; the bf16 image of the dequantised weights is dropped unless asked."""
+        if self.w8 is None:
+            raise _lib.UmvError("enable_fp8_mfma needs fp8 weights (from_weight_fp8 / from_gate_up_fp8)")
+        lib = _lib.load()
+        self.w8m = torch.empty(lib.umv_packed_weight_fp8_mfma_bytes(self.N, self.K), dtype=torch.uint8, device=self.w8.device)
+        check(lib.umv_repack_weight_fp8_mfma(_p(self.w8), _p(self.w8m), self.N, self.K, _stream()), "umv_repack_weight_fp8_mfma")
+        if not keep_bf16:
+            self.wp = None
+        return self
 
     @staticmethod
     def from_weight_fp8(w, bias=None):
@@ -201,6 +215,20 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
     if out is None:
         assert row_idx is None, "row-indexed GEMM writes into a caller-provided buffer"
         out = torch.empty((rows_out, n_out), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    if lin.w8m is not None and M > 64 and norm_w is None and not out_f32:
+        # W8A8: per-row e4m3 activations (rows gathered through row_idx), fp8 matrix instruction, exact pow2 scales
+        ldq = (lin.K + 127) // 128 * 128
+        xq = torch.empty((M, ldq), dtype=torch.uint8, device=x.device)
+        xs = torch.empty((M,), dtype=torch.float32, device=x.device)
+        check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), _p(xq), ldq, _p(xs), M, lin.K, _stream()), "umv_quantize_act_fp8")
+        a8 = _lib.Gemm8Args(
+            xq=xq.data_ptr(), ldq=ldq, x_scale=xs.data_ptr(), wp=lin.w8m.data_ptr(), w_scale=lin.scale.data_ptr(),
+            bias=lin.bias.data_ptr() if (flags & EPI_BIAS) else None,
+            residual=residual.data_ptr() if residual is not None else None,
+            ldr=residual.stride(0) if residual is not None else 0, out=out.data_ptr(), ldo=out.stride(0),
+            row_idx=row_idx.data_ptr() if row_idx is not None else None, M=M, N=lin.N, K=lin.K, epilogue=flags)
+        check(lib.umv_gemm_fp8a8w(C.byref(a8), _stream()), "umv_gemm_fp8a8w")
+        return out
     if lin.w8 is not None and M <= 64 and norm_w is None:
         a = GemmArgs(
             x=x.data_ptr(), ldx=x.stride(0), wp=lin.w8.data_ptr(),
@@ -316,6 +344,19 @@ class KVSlab:
     def strides(self):
         return dict(k_seg_stride=self.nkv * self.cap * self.hd, k_head_stride=self.cap * self.hd,
                     v_seg_stride=self.nkv * self.hd * self.cap, v_head_stride=self.hd * self.cap, v_d_stride=self.cap)
+
+
+def quantize_act(x, M=None, row_idx=None):
+    """Per-row e4m3 quantisation of bf16 activations (umv_quantize_act_fp8): returns (xq uint8 [M, ldq], scale f32 [M])."""
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    M = x.shape[0] if M is None else M
+    K = x.shape[1]
+    ldq = (K + 127) // 128 * 128
+    xq = torch.empty((M, ldq), dtype=torch.uint8, device=x.device)
+    xs = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), _p(xq), ldq, _p(xs), M, K, _stream()), "umv_quantize_act_fp8")
+    return xq, xs
 
 
 def gemm_splitk(x, lin, partials, k_splits, *, M=None):
