@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the whole run on e4m3 LLM weights (BASELINE.json configs[4]); the headline value is the bf16 run")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weights decode leg of the default run")
+    ap.add_argument("--fp8-act", type=int, default=1, help="fp8 leg: 1 = W8A8 (e4m3 activations on the fp8 MFMA) for prefill / flow "
+                    "passes, 0 = bf16 activations on the bf16 image of the dequantised weights")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -407,6 +409,7 @@ def main():
         torch.cuda.empty_cache()
         cfg8 = UniMedVLConfig.from_dict(cfg.to_dict())
         cfg8.llm_weight_dtype = "fp8"
+        cfg8.llm_act_dtype = "fp8" if args.fp8_act else "bf16"   # W8A8 on the fp8 matrix instruction for prefill / flow passes
         model8 = Bagel(cfg8, random_getter(cfg8, dev, seed=1234), device=dev, visual_gen=want_t2i, visual_und=True)
         l8 = decode_leg(model8)
         w8 = model8.language_model.w
@@ -421,11 +424,14 @@ def main():
             "workload": "configs[4]-style: same batch / context as the headline run, fp8 weights",
             "parity": "umv_gemm_fp8w == umv_gemm_bf16 on the dequantised weights bit for bit; engine vs the CPU oracle on the "
                       "dequantised weights at the bf16 tolerances (tests/test_fp8_gpu.py); split-K decode mode on"}
-        if want_t2i:   # the T2I half of configs[4]'s mixed batch on the same fp8-weight model: flow passes run the bf16 image of
-            # the dequantised weights on the MFMA path (M > 64), so this matches the bf16 T2I rate by construction
+        out["decode_fp8_weights"]["prefill_s"] = round(l8["t_prefill"], 3)
+        out["decode_fp8_weights"]["activations"] = ("decode steps: bf16; prefill / flow passes: per-row e4m3 on the fp8 matrix "
+                                                    "instruction (W8A8, umv_gemm_fp8a8w)") if args.fp8_act else "bf16 everywhere"
+        if want_t2i:   # the T2I half of configs[4]'s mixed batch on the same fp8 model
             l8["sess"] = l8["cache"] = None
             t8 = run_t2i(model8, cfg8, dev, rank, world, dist, num_timesteps=args.t2i_steps)
             out["decode_fp8_weights"]["t2i_images_per_s_same_model"] = t8["images_per_s"]
+            out["decode_fp8_weights"]["t2i_llm_tflops"] = t8["llm_tflops"]
         del model8, l8
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":

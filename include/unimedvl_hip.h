@@ -114,8 +114,10 @@ int umv_gemm_fp8w(const umv_gemm_args* a, umv_stream_t stream);
  * e4m3 image: P8M[n/16][k/128][(k%32)/16][lane = ((k%128)/32)*16 + n%16][k%16]. */
 size_t umv_packed_weight_fp8_mfma_bytes(int N, int K);
 int umv_repack_weight_fp8_mfma(const uint8_t* packed8, uint8_t* out, int N, int K, umv_stream_t stream);
-int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_t* row_idx, uint8_t* xq, int64_t ldq, float* x_scale, int M,
-                         int K, umv_stream_t stream);
+/* deq (optional, row stride ldd): the dequantised rows as bf16 at their ORIGINAL positions (row_idx[m] when given) - the input
+ * of the M <= 64 kernels, which take bf16 activations; xq may then be NULL */
+int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_t* row_idx, uint8_t* xq, int64_t ldq, float* x_scale,
+                         uint16_t* deq, int64_t ldd, int M, int K, umv_stream_t stream);
 typedef struct {
     const uint8_t* xq;        /* [M, ldq] e4m3, rows 0..M-1 (already gathered) */
     int64_t ldq;

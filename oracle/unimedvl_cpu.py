@@ -141,9 +141,14 @@ class KVCache:
 # the model
 # ----------------------------------------------------------------------------
 class OracleBagel:
-    def __init__(self, cfg, sd, vae_sd=None, attn_impl="sdpa"):
+    def __init__(self, cfg, sd, vae_sd=None, attn_impl="sdpa", act_fp8=False):
         self.c = dict(cfg)
         self.sd = sd
+        # W8A8 mode of the fp8 extension (no reference counterpart, see oracle/fp8.py): every LLM forward that is not a
+        # one-token decode step rounds the inputs of its linear layers per row through e4m3; `sd` must already hold
+        # the dequantised weights (oracle.fp8.dequantised_weights)
+        self.act_fp8 = act_fp8
+        self._act8_now = False
         self.vae_sd = vae_sd
         self.attn_impl = attn_impl
         self.hidden = cfg["hidden"]
@@ -159,11 +164,19 @@ class OracleBagel:
     def _w(self, name):
         return self.sd[name]
 
+    def _lin(self, x, w, b=None):
+        """linear() of the LLM layers; in W8A8 mode on the per-row e4m3-rounded activations (umv_quantize_act_fp8)"""
+        if self._act8_now and x.shape[0] > 0:
+            from oracle.fp8 import quantize_act_rows
+            x = quantize_act_rows(x.to(BF16))[2]
+        return linear(x, w, b)
+
     def embed(self, ids):
         return self.sd["language_model.model.embed_tokens.weight"][ids]
 
     def _attn(self, l, x, query_lens, cos, sin, cache, update, is_causal, mode, text_idx, vae_idx):
         """qwen2_navit.py:525-626."""
+        linear = self._lin   # noqa: F841  (shadows the module-level helper: W8A8 mode rounds the inputs)
         c = self.c
         nh, nkv, hd = c["heads"], c["kv_heads"], self.head_dim
         p = f"language_model.model.layers.{l}.self_attn."
@@ -220,6 +233,7 @@ class OracleBagel:
         return o
 
     def _mlp(self, prefix, x):
+        linear = self._lin
         W = self._w
         g = linear(x, W(prefix + "gate_proj.weight"))
         u = linear(x, W(prefix + "up_proj.weight"))
@@ -233,6 +247,7 @@ class OracleBagel:
         W = self._w
         cos, sin = rope_cos_sin(position_ids, self.head_dim, c["rope_theta"], seq.dtype)
         query_lens = [int(x) for x in query_lens]
+        self._act8_now = bool(self.act_fp8) and max(query_lens) > 1
         for l in range(c["layers"]):
             p = f"language_model.model.layers.{l}."
             residual = seq

@@ -56,7 +56,7 @@ def test_w8a8_gemm_vs_dequantised_product(M, N, K):
     lin = ops.PackedLinear.from_weight_fp8(w.cuda(), b.cuda()).enable_fp8_mfma()
     assert lin.wp is None and lin.w8m.numel() == ((N + 15) // 16) * ((K + 127) // 128) * 2048
     res = torch.randn(M, N, generator=g).to(BF16)
-    got = ops.gemm(x.cuda(), lin, residual=res.cuda())
+    got = ops.gemm(x.cuda(), lin, residual=res.cuda(), act8=True)
     wd = fp8.quantize_rows(w)[2]
     xd = fp8.quantize_act_rows(x)[2]
     acc = (xd.cuda().double() @ wd.cuda().double().t()).float() + b.cuda().float()      # exact products, well-conditioned sum
@@ -76,7 +76,7 @@ def test_w8a8_swiglu_and_routing(M):
     lin = ops.PackedLinear.from_gate_up_fp8(gate.cuda(), up.cuda()).enable_fp8_mfma()
     idx = torch.randperm(M + 40, generator=g)[:M].to(torch.int32)
     out = torch.zeros(M + 40, I, dtype=BF16, device="cuda")
-    ops.gemm(x.cuda(), lin, out=out, M=M, row_idx=idx.cuda())
+    ops.gemm(x.cuda(), lin, out=out, M=M, row_idx=idx.cuda(), act8=True)
     xd = fp8.quantize_act_rows(x[idx.long()])[2].cuda().double()
     gd, ud = fp8.quantize_rows(gate)[2].cuda().double(), fp8.quantize_rows(up)[2].cuda().double()
     gg = (xd @ gd.t()).float().to(BF16).float()
@@ -88,9 +88,34 @@ def test_w8a8_swiglu_and_routing(M):
     assert not out[untouched.cuda()].any()
 
 
+@pytest.mark.parametrize("M", [1, 8, 40, 64])
+def test_w8a8_small_m_rounds_activations_too(M):
+    """M <= 64 rows run the weight-streaming kernels on a bf16 copy of the e4m3-rounded rows: same operands as the MFMA path."""
+    ops = _ops()
+    from oracle import fp8
+    g = torch.Generator().manual_seed(M)
+    K, N = 1024, 768
+    x = (torch.randn(M + 5, K, generator=g) * 2).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF16)
+    lin = ops.PackedLinear.from_weight_fp8(w.cuda()).enable_fp8_mfma()
+    idx = torch.randperm(M + 5, generator=g)[:M].to(torch.int32)
+    out = torch.zeros(M + 5, N, dtype=BF16, device="cuda")
+    ops.gemm(x.cuda(), lin, out=out, M=M, row_idx=idx.cuda(), act8=True)
+    xd = fp8.quantize_act_rows(x[idx.long()])[2].cuda().double()
+    ref = (xd @ fp8.quantize_rows(w)[2].cuda().double().t()).float().to(BF16)
+    _close(out[idx.long().cuda()], ref)
+    # without act8 the same linear still serves decode rows (bf16 activations), but refuses M > 64
+    ops.gemm(x.cuda(), lin, out=out, M=M, row_idx=idx.cuda())
+    from unimedvl_amd import _lib
+    with pytest.raises(_lib.UmvError, match="act8"):
+        ops.gemm(torch.randn(100, K).to(BF16).cuda(), lin)
+
+
 def test_w8a8_rejects_bad_arguments():
     ops = _ops()
     from unimedvl_amd import _lib
     lin = ops.PackedLinear.from_weight(torch.randn(64, 128).to(BF16).cuda())
     with pytest.raises(_lib.UmvError, match="fp8 weights"):
         lin.enable_fp8_mfma()
+    with pytest.raises(_lib.UmvError, match="act8 needs"):
+        ops.gemm(torch.randn(4, 128).to(BF16).cuda(), lin, act8=True)

@@ -74,8 +74,8 @@ class Gemm8Args(C.Structure):
 _SIGS = {
     "umv_packed_weight_fp8_mfma_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "umv_repack_weight_fp8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "umv_quantize_act_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
-                                       C.c_void_p]),
+    "umv_quantize_act_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int, C.c_int, C.c_void_p]),
     "umv_gemm_fp8a8w": (C.c_int, [C.POINTER(Gemm8Args), C.c_void_p]),
     "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
     "umv_version": (C.c_int, []),

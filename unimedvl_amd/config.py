@@ -22,6 +22,10 @@ class UniMedVLConfig:
     # "bf16" (the reference's precision) or "fp8": weight-only e4m3 with power-of-two channel scales for the LLM
     # linear layers and lm_head (BASELINE.json configs[4]; include/unimedvl_hip.h umv_quantize_pack_weight_fp8)
     llm_weight_dtype: str = "bf16"
+    # "fp8" (needs llm_weight_dtype == "fp8"): W8A8 - every LLM forward that is not a one-token decode step rounds the
+    # activations of its linear layers per row through e4m3 and runs them on the fp8 matrix instruction
+    # (umv_gemm_fp8a8w); decode steps keep bf16 activations on the e4m3 weight stream
+    llm_act_dtype: str = "bf16"
     # SigLIP NaViT (the scripts drop the last layer: interactive_vqa_inferencer.py:213)
     vit_hidden: int = 1152
     vit_layers: int = 26

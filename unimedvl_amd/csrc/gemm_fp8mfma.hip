@@ -63,11 +63,17 @@ __device__ __forceinline__ float act_pow2_scale(float amax) {   // smallest 2^e 
     return ldexpf(1.0f, ma <= 0.875f ? ea - 9 : ea - 8);
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 act_bf16x2_hw;
+
+// deq (optional): the dequantised row written back as bf16 at the ORIGINAL row position (same row_idx, row stride ldd), for
+// the M <= 64 kernels that take bf16 activations
 __global__ __launch_bounds__(256) void quantize_act_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, const int32_t* __restrict__ row_idx,
-                                                               uint8_t* __restrict__ xq, int64_t ldq, float* __restrict__ xs, int K) {
+                                                               uint8_t* __restrict__ xq, int64_t ldq, float* __restrict__ xs, int K,
+                                                               bf16_t* __restrict__ deq, int64_t ldd) {
     __shared__ float part[4];
     const int m = blockIdx.x;
-    const bf16_t* xr = x + (row_idx ? (int64_t)row_idx[m] : (int64_t)m) * ldx;
+    const int64_t srow = row_idx ? (int64_t)row_idx[m] : (int64_t)m;
+    const bf16_t* xr = x + srow * ldx;
     const int nv = K / 8;
     float mx = 0.f;
     for (int c = threadIdx.x; c < nv; c += 256) {
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void quantize_act_fp8_kernel(const bf16_t* __r
     const float s = act_pow2_scale(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
     if (threadIdx.x == 0) xs[m] = s;
     const float inv = 1.0f / s;
-    uint8_t* q = xq + (int64_t)m * ldq;
+    uint8_t* q = xq ? xq + (int64_t)m * ldq : nullptr;
     for (int c = threadIdx.x; c < (int)(ldq / 8); c += 256) {
         int lo = 0, hi = 0;
         if (c < nv) {
@@ -93,19 +99,28 @@ __global__ __launch_bounds__(256) void quantize_act_fp8_kernel(const bf16_t* __r
             lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
             hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
             hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+            if (deq) {
+                union { act_bf16x2_hw h[4]; bf16x8 v; } d;
+                d.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, s, false);
+                d.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, s, true);
+                d.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, s, false);
+                d.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, s, true);
+                *reinterpret_cast<bf16x8*>(deq + srow * ldd + c * 8) = d.v;
+            }
         }
         u32x2 o = {(uint32_t)lo, (uint32_t)hi};
-        *reinterpret_cast<u32x2*>(q + c * 8) = o;   // zero padded up to ldq
+        if (xq) *reinterpret_cast<u32x2*>(q + c * 8) = o;   // zero padded up to ldq
     }
 }
 
 extern "C" int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_t* row_idx, uint8_t* xq, int64_t ldq, float* x_scale,
-                                    int M, int K, umv_stream_t stream) {
-    UMV_CHECK(x && xq && x_scale && M >= 0 && K > 0, UMV_ERR_ARG, "quantize_act_fp8: bad args");
+                                    uint16_t* deq, int64_t ldd, int M, int K, umv_stream_t stream) {
+    UMV_CHECK(x && (xq || deq) && x_scale && M >= 0 && K > 0, UMV_ERR_ARG, "quantize_act_fp8: bad args");
+    UMV_CHECK(!deq || (ldd % 8) == 0, UMV_ERR_ARG, "quantize_act_fp8: ldd must be a multiple of 8");
     UMV_CHECK((K % 8) == 0 && (ldx % 8) == 0 && (ldq % 128) == 0 && ldq >= K, UMV_ERR_ARG,
               "quantize_act_fp8: K (%d), ldx must be multiples of 8 and ldq (%lld) a multiple of 128 >= K", K, (long long)ldq);
     if (M == 0) return UMV_OK;
-    hipLaunchKernelGGL(quantize_act_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, row_idx, xq, ldq, x_scale, K);
+    hipLaunchKernelGGL(quantize_act_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, row_idx, xq, ldq, x_scale, K, deq, ldd);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }

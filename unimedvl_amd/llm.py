@@ -130,17 +130,20 @@ class Qwen2MoT:
         main = torch.cuda.current_stream()
         side = self._side_stream() if (gen and self.overlap_experts) else None
 
+        # W8A8 mode: every forward that is not a one-token decode step rounds its linear-layer inputs per row through e4m3
+        act8 = bool(getattr(w, "act8", False)) and max_q > 1
+
         def routed(xin, und_lin, gen_lin, out, residual=None):
             if not gen:
-                return ops.gemm(xin, und_lin, out=out, residual=residual)
+                return ops.gemm(xin, und_lin, out=out, residual=residual, act8=act8)
             if side is None:
-                ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual)
-                ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual)
+                ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual, act8=act8)
+                ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual, act8=act8)
                 return out
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual)
-            ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual)
+                ops.gemm(xin, und_lin, out=out, M=n_text, row_idx=text_rows, residual=residual, act8=act8)
+            ops.gemm(xin, gen_lin, out=out, M=n_vae, row_idx=vae_rows, residual=residual, act8=act8)
             main.wait_stream(side)
             return out
 

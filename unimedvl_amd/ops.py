@@ -188,9 +188,11 @@ def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_b
 
 
 def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
-         norm_w=None, norm_eps=1e-6):
+         norm_w=None, norm_eps=1e-6, act8=False):
     """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
-    norm_w: fuse Qwen2RMSNorm(x)*norm_w into the GEMM prologue (M <= 16, K <= 4096)."""
+    norm_w: fuse Qwen2RMSNorm(x)*norm_w into the GEMM prologue (M <= 16, K <= 4096).
+    act8 (W8A8 mode, needs lin.w8m): the activations are rounded per row through e4m3 - on the fp8 matrix instruction for
+    M > 64 rows, as a bf16 copy of the rounded rows for the weight-streaming kernels below that."""
     lib = _lib.load()
     _req(x, BF16, "x")
     assert x.stride(-1) == 1
@@ -215,12 +217,19 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
     if out is None:
         assert row_idx is None, "row-indexed GEMM writes into a caller-provided buffer"
         out = torch.empty((rows_out, n_out), dtype=torch.float32 if out_f32 else BF16, device=x.device)
-    if lin.w8m is not None and M > 64 and norm_w is None and not out_f32:
+    if act8 and lin.w8m is None:
+        raise _lib.UmvError("act8 needs a linear with the fp8-MFMA image (enable_fp8_mfma)")
+    if act8 and M <= 64:
+        x = fake_quantize_act(x, M, row_idx)
+    if lin.wp is None and not (act8 and M > 64) and not (lin.w8 is not None and M <= 64 and norm_w is None):
+        raise _lib.UmvError(f"this linear only has fp8 images: M={M} rows need act8=True (W8A8) - the bf16 image was dropped")
+    if act8 and M > 64 and norm_w is None and not out_f32:
         # W8A8: per-row e4m3 activations (rows gathered through row_idx), fp8 matrix instruction, exact pow2 scales
         ldq = (lin.K + 127) // 128 * 128
         xq = torch.empty((M, ldq), dtype=torch.uint8, device=x.device)
         xs = torch.empty((M,), dtype=torch.float32, device=x.device)
-        check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), _p(xq), ldq, _p(xs), M, lin.K, _stream()), "umv_quantize_act_fp8")
+        check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), _p(xq), ldq, _p(xs), None, 0, M, lin.K, _stream()),
+              "umv_quantize_act_fp8")
         a8 = _lib.Gemm8Args(
             xq=xq.data_ptr(), ldq=ldq, x_scale=xs.data_ptr(), wp=lin.w8m.data_ptr(), w_scale=lin.scale.data_ptr(),
             bias=lin.bias.data_ptr() if (flags & EPI_BIAS) else None,
@@ -355,8 +364,22 @@ def quantize_act(x, M=None, row_idx=None):
     ldq = (K + 127) // 128 * 128
     xq = torch.empty((M, ldq), dtype=torch.uint8, device=x.device)
     xs = torch.empty((M,), dtype=torch.float32, device=x.device)
-    check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), _p(xq), ldq, _p(xs), M, K, _stream()), "umv_quantize_act_fp8")
+    check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), _p(xq), ldq, _p(xs), None, 0, M, K, _stream()), "umv_quantize_act_fp8")
     return xq, xs
+
+
+def fake_quantize_act(x, M=None, row_idx=None):
+    """bf16 copy of x whose rows (row_idx[m] when given, the others are left undefined) are rounded through the per-row e4m3
+    grid: the activations of the W8A8 mode for the M <= 64 kernels, which take bf16 inputs."""
+    lib = _lib.load()
+    _req(x, BF16, "x")
+    M = x.shape[0] if M is None else M
+    out = torch.empty_like(x)
+    xs = torch.empty((M,), dtype=torch.float32, device=x.device)
+    ldq = (x.shape[1] + 127) // 128 * 128
+    check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), None, ldq, _p(xs), _p(out), out.stride(0), M, x.shape[1], _stream()),
+          "umv_quantize_act_fp8")
+    return out
 
 
 def gemm_splitk(x, lin, partials, k_splits, *, M=None):
@@ -368,8 +391,8 @@ def gemm_splitk(x, lin, partials, k_splits, *, M=None):
     M = x.shape[0] if M is None else M
     assert partials.dim() == 3 and partials.shape[0] == k_splits and partials.shape[2] == lin.N and partials.is_contiguous()
     assert lin.th == 16 and not lin.swiglu
-    a = GemmArgs(x=x.data_ptr(), ldx=x.stride(0), wp=lin.wp.data_ptr(), out=partials.data_ptr(), ldo=lin.N, M=M, N=lin.N, K=lin.K,
-                 epilogue=0, tile_rows=0, k_splits=k_splits, split_stride=partials.stride(0))
+    a = GemmArgs(x=x.data_ptr(), ldx=x.stride(0), wp=None if lin.wp is None else lin.wp.data_ptr(), out=partials.data_ptr(), ldo=lin.N,
+                 M=M, N=lin.N, K=lin.K, epilogue=0, tile_rows=0, k_splits=k_splits, split_stride=partials.stride(0))
     if lin.w8 is not None:   # e4m3 image: same split, same consumers
         a.wp, a.w_scale = lin.w8.data_ptr(), lin.scale.data_ptr()
         check(lib.umv_gemm_fp8w(C.byref(a), _stream()), "umv_gemm_fp8w")

@@ -38,11 +38,19 @@ class LLMWeights:
         if cfg.llm_weight_dtype not in ("bf16", "fp8"):
             raise ValueError(f"llm_weight_dtype must be 'bf16' or 'fp8', got {cfg.llm_weight_dtype!r}")
         fp8 = self.fp8 = cfg.llm_weight_dtype == "fp8"
+        if cfg.llm_act_dtype not in ("bf16", "fp8") or (cfg.llm_act_dtype == "fp8" and not fp8):
+            raise ValueError("llm_act_dtype must be 'bf16', or 'fp8' together with llm_weight_dtype='fp8'")
+        self.act8 = cfg.llm_act_dtype == "fp8"
         self.embed = _dev(get(p + "embed_tokens.weight"), device)
         self.und, self.gen = [], []
         for l in range(cfg.layers):
             self.und.append(self._layer(get, device, p + f"layers.{l}.", "", fp8))
             self.gen.append(self._layer(get, device, p + f"layers.{l}.", "_moe_gen", fp8) if load_gen else None)
+            if self.act8:   # W8A8: the fp8-MFMA image replaces the bf16 image of the dequantised weights
+                for lw in (self.und[-1], self.gen[-1]):
+                    if lw is not None:
+                        for lin in (lw.qkv, lw.o, lw.gate_up, lw.down):
+                            lin.enable_fp8_mfma()
         self.norm = _dev(get(p + "norm.weight"), device)
         self.norm_gen = _dev(get(p + "norm_moe_gen.weight"), device) if load_gen else None
         self.lm_head = _linear(get, device, "language_model.lm_head.weight", fp8=fp8)
