@@ -45,7 +45,8 @@ def _close(got, ref, mag=None):
     assert (got == ref).float().mean() >= 0.97
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 256, 512), (1000, 1152, 1024), (2048, 3584, 3584), (129, 320, 200), (65, 48, 128), (700, 4608, 3584)])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 512), (1000, 1152, 1024), (2048, 3584, 3584), (129, 320, 200), (65, 48, 128), (700, 4608, 3584),
+                                   (3072, 3584, 512), (3001, 3100, 200)])   # the last two: >= 144 tiles of 256 x 256 -> the big tile
 def test_w8a8_gemm_vs_dequantised_product(M, N, K):
     ops = _ops()
     from oracle import fp8

@@ -26,12 +26,12 @@ def bench(M, N, K, swiglu=False, reps=20):
         lin.enable_fp8_mfma()
     out = torch.empty(M, N // 2 if swiglu else N, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
-        ops.gemm(x, lin, out=out)
+        ops.gemm(x, lin, out=out, act8=FP8)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.gemm(x, lin, out=out)
+        ops.gemm(x, lin, out=out, act8=FP8)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
@@ -46,7 +46,7 @@ FLOW = [(3072, 4608, 3584, False), (3072, 3584, 3584, False), (3072, 37888, 3584
         (2048, 3584, 18944, False), (2048, 4608, 3584, False), (2048, 3584, 3584, False)]
 
 if __name__ == "__main__":
-    tag = os.environ.get("UMV_GEMM_TILE", "auto")
+    tag = os.environ.get("UMV_GEMM8_TILE" if FP8 else "UMV_GEMM_TILE", "auto")
     for M, N, K, sw in (FLOW if "--flow" in sys.argv else PREFILL):
         us, tf = bench(M, N, K, sw)
         print(f"tile={tag:>4s} M={M:5d} N={N:6d} K={K:6d} {'swiglu' if sw else '      '} {us:9.1f} us {tf:8.1f} TF/s", flush=True)

@@ -278,12 +278,16 @@ extern "C" int umv_gemm_fp8a8w(const umv_gemm8_args* ap, umv_stream_t stream) {
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 127) / 128, NTT = (a.N + 15) / 16;
-    static int force = -1;   // tuning only: UMV_GEMM8_TILE=<256|258|128>
+    static int force = -1;   // tuning only: UMV_GEMM8_TILE=<256|258|259|128>
     if (force < 0) { const char* e = getenv("UMV_GEMM8_TILE"); force = e ? atoi(e) : 0; }
+    // Measured (tools/gemm_bench.py --fp8): the 256 x 256 tile wins once it gives >= ~144 workgroups (M=2048,N=4608: 69.6 vs
+    // 77.4 us); below that the 256 x 128 tile with three stage buffers does (M=1024,N=3584,K=18944: 159 vs 251 us), and its
+    // third buffer is worth 5-10% over two on every shape.
     const long wg256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    int cfg = wg256 >= 160 ? 256 : 258;
+    int cfg = wg256 >= 144 ? 256 : 259;
     if (force) cfg = force;
     if (cfg == 256) return launch_tiled8<2, 4, 8, 4, 2>(a, KT, NTT, s);   // 256 x 256 x 128, 2 buffers of 64 KiB
     if (cfg == 128) return launch_tiled8<2, 2, 4, 4, 2>(a, KT, NTT, s);   // 128 x 128 x 128, 2 buffers of 32 KiB
-    return launch_tiled8<4, 2, 4, 4, 2>(a, KT, NTT, s);                   // 256(n) x 128(m) x 128, 2 buffers of 48 KiB
+    if (cfg == 258) return launch_tiled8<4, 2, 4, 4, 2>(a, KT, NTT, s);   // 256(n) x 128(m) x 128, 2 buffers of 48 KiB
+    return launch_tiled8<4, 2, 4, 4, 3>(a, KT, NTT, s);                   // 256(n) x 128(m) x 128, 3 buffers (144 KiB)
 }
