@@ -267,6 +267,12 @@ typedef struct {
     float eps;
     int nsplit;
     void* workspace;       /* umv_attn_workspace_bytes(nseg, nq, hd, 1, nsplit) when nsplit > 1 */
+    /* optional: the QKV row as the fp32 partial sums of a split-K umv_gemm_bf16 / umv_gemm_fp8w (then `qkv` may be NULL):
+     * x = bf16(sum_s P[s][row][col] + bias[col]), exactly what umv_qkv_post does with the same fields */
+    const float* qkv_partials; /* [n_splits][nseg, (nq + 2 nkv) * hd] fp32, row stride ld_qkv, split stride split_stride */
+    int n_splits;
+    int64_t split_stride;
+    const uint16_t* qkv_bias;  /* [(nq + 2 nkv) * hd] or NULL (only read with qkv_partials) */
 } umv_attn_decode_args;
 int umv_attn_decode_fused(const umv_attn_decode_args* a, umv_stream_t stream);
 

@@ -62,3 +62,46 @@ def test_fused_decode_attention_matches_two_kernel_path(nsplit):
     tol = ref.float().abs() * 2.0 ** -7 + 2e-3 * ref.float().abs().max()
     assert (d <= tol).all(), f"max diff {d.max().item()}"
     assert (got == ref).float().mean() > 0.97
+
+
+@pytest.mark.parametrize("n_splits,with_bias", [(1, False), (3, True), (4, False)])
+def test_fused_decode_attention_from_splitk_partials(n_splits, with_bias):
+    """QKV row handed over as the fp32 partial sums of a split-K GEMM: the kernel's own sum (split order, + bias, one bf16
+    rounding) must give bit for bit what it gives on the bf16 row holding those sums."""
+    ops = _ops()
+    nq, nkv, hd = 28, 4, 128
+    lens = [1, 33, 64, 100, 777, 1060]
+    B = len(lens)
+    g = torch.Generator().manual_seed(n_splits)
+    cap, nsplit = 1088, 17
+    N = (nq + 2 * nkv) * hd
+    part = torch.randn(n_splits, B, N, generator=g).cuda()
+    bias = torch.randn(N, generator=g).to(BF16).cuda() if with_bias else None
+    acc = torch.zeros(B, N, device="cuda")
+    for s in range(n_splits):
+        acc = acc + part[s]
+    if with_bias:
+        acc = acc + bias.float()
+    qkv = acc.to(BF16)
+    qn = (1 + 0.1 * torch.randn(hd, generator=g)).to(BF16).cuda()
+    kn = (1 + 0.1 * torch.randn(hd, generator=g)).to(BF16).cuda()
+    ang = torch.rand(2048, hd, generator=g) * 6.28
+    cos, sin = ang.cos().to(BF16).cuda(), ang.sin().to(BF16).cuda()
+    pos = torch.tensor([l + 3 for l in lens], dtype=torch.int32).cuda()
+    kv_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    cu = torch.arange(B + 1, dtype=torch.int32).cuda()
+    hist_k = torch.randn(B, nkv, cap, hd, generator=g).to(BF16)
+    hist_v = torch.randn(B, nkv, hd, cap, generator=g).to(BF16)
+    ws = ops.attn_workspace(B, nq, hd, 1, nsplit, "cuda")
+    outs = []
+    for kw in (dict(), dict(partials=part, bias=bias)):
+        slab = ops.KVSlab(B, nkv, cap, hd, "cuda")
+        slab.k.copy_(hist_k)
+        slab.vt.copy_(hist_v)
+        out = torch.zeros(B, nq * hd, dtype=BF16, device="cuda")
+        ops.attn_decode_fused(None if kw else qkv, out, slab, cu, kv_len, pos, nq, nkv, hd, 1e-6, qn, kn, cos, sin, nsplit, ws, **kw)
+        torch.cuda.synchronize()
+        outs.append((out, slab.k.clone(), slab.vt.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert outs[0][0].abs().sum() > 0

@@ -137,8 +137,10 @@ def test_decode_session_splitk_matches_default(tiny_weights, monkeypatch):
             return prompts[int(s)]
 
     runs = {}
-    for mode in ("0", "2,2,3"):
-        monkeypatch.setenv("UMV_DECODE_SPLITK", mode)
+    modes = ("0", "2,2,3", "3,1,2", "nofuse:2,1,3")   # every GEMM split or not, partial sums into the fused attention or qkv_post
+    for mode in modes:
+        monkeypatch.setenv("UMV_DECODE_FUSE_ATTN", "0" if mode.startswith("nofuse:") else "1")
+        monkeypatch.setenv("UMV_DECODE_SPLITK", mode.split(":")[-1])
         cache = NaiveCache(cfg["layers"])
         gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], Tok(), NEW_TOKEN_IDS)
         cache = model.forward_cache_update_text(cache, **gi)
@@ -147,21 +149,23 @@ def test_decode_session_splitk_matches_default(tiny_weights, monkeypatch):
             from copy import deepcopy
             sess = DecodeSession(model.language_model, deepcopy(cache), gi["packed_start_tokens"], gi["packed_query_position_ids"], 6,
                                  use_graph=use_graph)
-            assert (sess.sk is not None) == (mode != "0")
+            assert sess.sk == ((1, 1, 1) if mode == "0" else tuple(int(v) for v in mode.split(":")[-1].split(",")))
+            assert sess.fuse_attn == (not mode.startswith("nofuse:"))
             logits = []
             for _ in range(5):
                 sess.step(1)
                 logits.append(sess.logits.float().clone())
             runs[(mode, use_graph)] = (sess.pred_ids[:5].clone(), torch.stack(logits))
-    for mode in ("0", "2,2,3"):   # graph replay == eager, bit for bit, in both modes
+    for mode in modes:   # graph replay == eager, bit for bit, in every mode
         assert torch.equal(runs[(mode, False)][0], runs[(mode, True)][0])
         assert torch.equal(runs[(mode, False)][1], runs[(mode, True)][1])
     ids0, lg0 = runs[("0", False)]
-    ids1, lg1 = runs[("2,2,3", False)]
-    for s in range(5):
-        assert (lg0[s] - lg1[s]).abs().max() <= 0.25
-        top2 = lg0[s].topk(2, dim=-1).values
-        sure = (top2[:, 0] - top2[:, 1]) > 0.25
-        assert torch.equal(ids0[s][sure], ids1[s][sure])
-        if not torch.equal(ids0[s], ids1[s]):
-            break
+    for mode in modes[1:]:
+        ids1, lg1 = runs[(mode, False)]
+        for s in range(5):
+            assert (lg0[s] - lg1[s]).abs().max() <= 0.25
+            top2 = lg0[s].topk(2, dim=-1).values
+            sure = (top2[:, 0] - top2[:, 1]) > 0.25
+            assert torch.equal(ids0[s][sure], ids1[s][sure])
+            if not torch.equal(ids0[s], ids1[s]):
+                break

@@ -28,7 +28,7 @@ def timed(fn, reps):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    exact = os.environ.get("EXACT", "1") != "0"
+    exact = os.environ.get("EXACT", "1") != "0" and int(os.environ.get("SPLIT", "0")) <= 1   # split-K uses the 16-row tiles
     fp8 = os.environ.get("FP8", "0") != "0"
     norm = os.environ.get("NORM", "0") != "0"   # fused RMSNorm prologue (K <= 4096 shapes only)
     dec = os.environ.get("DEC", "0") != "0"     # persistent decode GEMM (umv_gemm_decode) on the decode image
@@ -55,6 +55,10 @@ def main():
         out = torch.empty(B, N // 2 if swiglu else N, device="cuda", dtype=BF16)
         nw = torch.ones(K, device="cuda", dtype=BF16) if (norm and K <= 4096) else None
         mm = ops.gemm_decode if dec else ops.gemm
+        split = int(os.environ.get("SPLIT", "0"))   # split-K mode (fp32 partials, finished by the consumer kernel)
+        if split > 1 and not swiglu:
+            part = torch.empty(split, B, N, device="cuda", dtype=torch.float32)
+            mm = lambda x, lin, out=None, norm_w=None: ops.gemm_splitk(x, lin, part, split)   # noqa: E731
         for lin in lins:
             mm(x, lin, out=out, norm_w=nw)
         cold = timed(lambda i: mm(x, lins[i % ncopies], out=out, norm_w=nw), 10 * ncopies)

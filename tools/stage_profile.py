@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Run ONE stage of the path repeatedly at the 14B dims so that a rocprofv3 kernel trace isolates it:
+    python tools/stage_profile.py vit [B]        ViT tower + connector on B 448x448 images
+    python tools/stage_profile.py prefill [B]    forward_cache_update_vit + forward_cache_update_text (image span + question)
+Prints the wall time per repetition; under `rocprofv3 --kernel-trace --stats` the per-kernel table is that stage's alone
+(plus the one-time weight initialisation, which only uses torch / pack kernels)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import IdTokenizer, synth_image  # noqa: E402
+from unimedvl_amd.bagel import Bagel  # noqa: E402
+from unimedvl_amd.config import UniMedVLConfig  # noqa: E402
+from unimedvl_amd.kvcache import NaiveCache  # noqa: E402
+from unimedvl_amd.weights import random_getter  # noqa: E402
+
+
+def main():
+    stage = sys.argv[1] if len(sys.argv) > 1 else "vit"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    reps = int(os.environ.get("REPS", "10"))
+    dev = torch.device("cuda", 0)
+    cfg = UniMedVLConfig()
+    cfg.llm_weight_dtype = os.environ.get("WEIGHTS", "bf16")
+    if os.environ.get("ACT8", "0") != "0":
+        cfg.llm_act_dtype = "fp8"
+    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=False, visual_und=True)
+    ids = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
+    images = [synth_image(448, 448, i) for i in range(B)]
+    g = torch.Generator().manual_seed(1234)
+    prompts = [torch.randint(1000, 150000, (32,), generator=g).tolist() for _ in range(B)]
+
+    def vit():
+        gi, _, _ = model.prepare_vit_images([0] * B, [0] * B, images, lambda x: x, ids)
+        px, pos = gi["packed_vit_tokens"].to(dev), gi["packed_vit_position_ids"].to(dev)
+        return lambda: model.encode_vit(px, pos, gi["vit_token_seqlens"])
+
+    def prefill():
+        def run():
+            cache = NaiveCache(cfg.layers)
+            gi, kvl, rope = model.prepare_vit_images([0] * B, [0] * B, images, lambda x: x, ids)
+            cache.reserve(B, max(kvl) + 64, cfg.kv_heads, cfg.head_dim, dev)
+            cache = model.forward_cache_update_vit(cache, **gi)
+            gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), ids)
+            model.forward_cache_update_text(cache, **gi)
+        return run
+
+    fn = {"vit": vit, "prefill": prefill}[stage]()
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    print(f"{stage} B={B}: {(time.time() - t0) / reps * 1e3:.3f} ms per repetition ({reps} reps)")
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,7 @@ class AttnDecodeArgs(C.Structure):
         ("v_head_stride", C.c_int64), ("v_d_stride", C.c_int64),
         ("nseg", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("eps", C.c_float), ("nsplit", C.c_int),
         ("workspace", C.c_void_p),
+        ("qkv_partials", C.c_void_p), ("n_splits", C.c_int), ("split_stride", C.c_int64), ("qkv_bias", C.c_void_p),
     ]
 
 

@@ -460,15 +460,25 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
 
 
 def attn_decode_fused(qkv, out, slab, cu_q, kv_len, tok_pos, nq, nkv, hd, eps, q_norm, k_norm, cos_tab, sin_tab, nsplit=1,
-                      workspace=None):
-    """One decode step: q/k norm + RoPE + KV append + attention over kv_len keys, from the raw fused QKV rows."""
+                      workspace=None, partials=None, bias=None):
+    """One decode step: q/k norm + RoPE + KV append + attention over kv_len keys, from the raw fused QKV rows (`qkv` bf16)
+    or from the fp32 partial sums [n_splits, B, (nq+2nkv)*hd] of a split-K QKV GEMM (`partials`, + `bias`)."""
     lib = _lib.load()
-    _req(qkv, BF16, "qkv")
+    extra = {}
+    if partials is not None:
+        _req(partials, torch.float32, "partials")
+        if partials.dim() != 3 or partials.stride(2) != 1:
+            raise _lib.UmvError("attn_decode_fused: partials must be [n_splits, B, (nq+2nkv)*hd] with unit column stride")
+        extra = dict(qkv=None, ld_qkv=partials.stride(1), qkv_partials=partials.data_ptr(), n_splits=partials.shape[0],
+                     split_stride=partials.stride(0), qkv_bias=None if bias is None else bias.data_ptr())
+    else:
+        _req(qkv, BF16, "qkv")
+        extra = dict(qkv=qkv.data_ptr(), ld_qkv=qkv.stride(0))
     a = _lib.AttnDecodeArgs(
-        qkv=qkv.data_ptr(), ld_qkv=qkv.stride(0), out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
+        out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
         tok_pos=tok_pos.data_ptr(), q_norm_w=q_norm.data_ptr(), k_norm_w=k_norm.data_ptr(), cos_tab=cos_tab.data_ptr(),
         sin_tab=sin_tab.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
-        eps=eps, nsplit=nsplit, workspace=None if workspace is None else workspace.data_ptr(), **slab.strides())
+        eps=eps, nsplit=nsplit, workspace=None if workspace is None else workspace.data_ptr(), **extra, **slab.strides())
     check(lib.umv_attn_decode_fused(C.byref(a), _stream()), "umv_attn_decode_fused")
     return out
 
