@@ -47,6 +47,10 @@ FLOW = [(3072, 4608, 3584, False), (3072, 3584, 3584, False), (3072, 37888, 3584
 
 if __name__ == "__main__":
     tag = os.environ.get("UMV_GEMM8_TILE" if FP8 else "UMV_GEMM_TILE", "auto")
-    for M, N, K, sw in (FLOW if "--flow" in sys.argv else PREFILL):
+    shapes = FLOW if "--flow" in sys.argv else PREFILL
+    if os.environ.get("SHAPE"):   # SHAPE=M,N,K[,swiglu]: one shape only (counter collection)
+        v = os.environ["SHAPE"].split(",")
+        shapes = [(int(v[0]), int(v[1]), int(v[2]), len(v) > 3)]
+    for M, N, K, sw in shapes:
         us, tf = bench(M, N, K, sw)
         print(f"tile={tag:>4s} M={M:5d} N={N:6d} K={K:6d} {'swiglu' if sw else '      '} {us:9.1f} us {tf:8.1f} TF/s", flush=True)

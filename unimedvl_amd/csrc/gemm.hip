@@ -672,13 +672,30 @@ __device__ __attribute__((aligned(16))) const uint32_t g_zero_page[4] = {0, 0, 0
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// inline-asm building blocks of the interleaved schedule (free functions: clang rejects asm operands that name locals of
+// the enclosing function from inside a generic lambda)
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// read r of NRD goes right after MFMA number (r * NMMA) / NRD of NMMA: evenly spread, first one after the first MFMA
+constexpr int interleave_slot(int i, int nmma, int nrd) {
+    for (int r = 0; r < nrd; ++r)
+        if ((r * nmma) / nrd == i) return r;
+    return -1;
+}
+__device__ __forceinline__ void mfma16_asm(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
 // WN x WM waves, each owning TN x TM MFMA tiles: workgroup tile (WN*TN*16)(n) x (WM*TM*16)(m) x (KTS*32)(k),
 // NBUF LDS buffers.  Pipeline per k-step t (one raw s_barrier, never a full vmcnt drain in steady state):
 //     s_waitcnt vmcnt((NBUF-2) tiles)   my part of tile t has landed, tiles t+1.. stay in flight
 //     s_barrier                         everyone's part of tile t landed AND everyone finished reading tile t-1
 //     issue LDS-DMA for tile t+NBUF-1   into the buffer tile t-1 just vacated
 //     ds_read fragments of tile t, MFMAs
-template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int PRIO = 0>
+// SCHED = 1: the same pipeline with the MFMAs of tile t and the ds_reads of tile t+1 interleaved by hand (see below).
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
@@ -729,21 +746,43 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         }
     }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    // Fast path of the staging (every k-step but a ragged last one): one pointer bump per tile, no branches - this code
+    // sits between the barrier and the first MFMA of every step.  A tile of n-rows past N reads the zero page with a zero
+    // bump.  Steps are staged in order, so the pointers advance incrementally.
+    const bf16_t* cur[TPW];
+    int bump[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int f = wave * TPW + i;
+        cur[i] = tvalid[i] ? src[i] : zero;
+        bump[i] = !tvalid[i] ? 0 : (f < WTILES ? KTS * 512 : KTS * 32);
+    }
+    const bool ragged = (KT % KTS) != 0 || (a.K & 31) != 0;     // the last k-step needs per-tile / per-lane zero fill
     auto stage = [&](int step, int buf) {
+        if (ragged && step == nsteps - 1) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int f = wave * TPW + i;
+                const bf16_t* p;
+                if (f < WTILES) {
+                    const int kt = step * KTS + f % KTS;
+                    p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)step * (KTS * 512) : zero;
+                } else {
+                    const int kt = step * KTS + (f - WTILES) % KTS;
+                    const int k = kt * 32 + g * 8;
+                    p = (k < a.K) ? src[i] + (int64_t)step * (KTS * 32) : zero;
+                }
+                char* dst = smem + buf * BUF + f * 1024;
+                __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_t)dst, 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int f = wave * TPW + i;
-            const bf16_t* p;
-            if (f < WTILES) {
-                const int kt = step * KTS + f % KTS;
-                p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)step * (KTS * 512) : zero;
-            } else {
-                const int kt = step * KTS + (f - WTILES) % KTS;
-                const int k = kt * 32 + g * 8;
-                p = (k < a.K) ? src[i] + (int64_t)step * (KTS * 32) : zero;
-            }
             char* dst = smem + buf * BUF + f * 1024;
-            __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)cur[i], (lds_ptr_t)dst, 16, 0, 0);
+            cur[i] += bump[i];
         }
     };
     f32x4 acc[TN][TM];
@@ -755,55 +794,68 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
     for (int p = 0; p < NBUF - 1; ++p)
         if (p < nsteps) stage(p, p);
-    if constexpr (PRIO == 2) {
-        // Register double buffering (KTS == 1): the fragments of tile t+1 are read from LDS while the MFMAs of
-        // tile t run out of registers, so the matrix pipe does not wait for ds_read latency after each barrier.
-        static_assert(PRIO != 2 || (KTS == 1 && NBUF >= 3), "fragment double buffering needs KTS == 1 and >= 3 LDS buffers");
-        // The LDS reads are inline asm with a MANUAL s_waitcnt: left to the compiler, the loop-carried fragments get a
-        // conservative `s_waitcnt lgkmcnt(0)` right after the next tile's ds_reads are issued (seen in the ISA), which
-        // serialises exactly what this variant is meant to overlap.
+    if constexpr (SCHED == 1) {
+        // Interleaved schedule (KTS == 1).  With the plain loop every wave leaves the barrier, issues its 12 ds_read_b128
+        // at once and only then its 32 MFMAs: the 8 waves' 96 KiB of fragment reads keep the LDS pipe busy for ~768
+        // cycles during which the matrix pipes mostly wait, then LDS idles for the ~1024 cycles of MFMAs - the two phases
+        // add up (MfmaUtil 44 % from the PMC counters).  Here the fragments of tile t+1 are requested one ds_read at a
+        // time, spread evenly between the MFMAs of tile t (every 2-3 MFMAs for the 256 x 256 tile), so each wave starts its MFMAs right after the barrier and the LDS traffic is spread
+        // over the whole step.  MFMAs and ds_reads are inline asm so that the order is exactly the one written.
+        static_assert(SCHED != 1 || (KTS == 1 && NBUF >= 3), "interleaved schedule needs KTS == 1 and >= 3 LDS buffers");
         bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
         const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-        auto ldfrag = [&](int buf, bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
-            const uint32_t wa = lds0 + buf * BUF + wn * TN * 1024 + lane * 16;
-            const uint32_t xa = lds0 + buf * BUF + WTILES * 1024 + wm * TM * 1024 + lane * 16;
-#pragma unroll
-            for (int t = 0; t < TN; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(wf[t]) : "v"(wa + t * 1024));
-#pragma unroll
-            for (int j = 0; j < TM; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(xa + j * 1024));
+        const uint32_t woff = wn * TN * 1024 + lane * 16, xoff = WTILES * 1024 + wm * TM * 1024 + lane * 16;
+        auto wait_tiles = [&](int allowed) {   // tiles (of TPW DMA ops each) that may stay in flight
+            if (allowed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
+            else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
-        // the fragments issued one step earlier have landed; the "+v" ties order every later use after the wait
-        auto wait_frags = [&](bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
+        auto land = [&](bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {   // all fragment reads issued so far have landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(wf[t]));
 #pragma unroll
             for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
         };
-        auto wait_tiles = [&](int allowed) {   // tiles (of TPW DMA ops each) that may stay in flight
-            if (allowed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
-            else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
         wait_tiles(min(NBUF - 2, nsteps - 1));
         __builtin_amdgcn_s_barrier();
-        ldfrag(0, wfA, xfA);
+        static_for<0, TN>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            lds_read_frag<t * 1024>(wfA[t], lds0 + woff);
+        });
+        static_for<0, TM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            lds_read_frag<j * 1024>(xfA[j], lds0 + xoff);
+        });
+        land(wfA, xfA);
+        constexpr int NRD = TN + TM, NMMA = TN * TM;
+        static_assert(SCHED != 1 || NRD <= NMMA, "at most one fragment read per MFMA");
         auto body = [&](int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
-            const bool more = step + 1 < nsteps;
-            if (more) wait_tiles(min(NBUF - 3, nsteps - 2 - step));      // tile step+1 landed (mine)
+            if (step + 1 < nsteps) wait_tiles(min(NBUF - 3, nsteps - 2 - step));      // tile step+1 landed (mine)
             __builtin_amdgcn_s_barrier();                                // ... everyone's; and tile step-1's buffer is free
             if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
-            wait_frags(wc, xc);
-            if (more) ldfrag((step + 1) % NBUF, wnx, xnx);
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-#pragma unroll
-                for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wc[t], xc[j], acc[t][j]);
+            // the reads of the last step fetch a tile nobody uses (the buffer exists): no branch inside the sequence
+            const uint32_t nb = lds0 + ((step + 1) % NBUF) * BUF;
+            const uint32_t wa = nb + woff, xa = nb + xoff;
+            static_for<0, NMMA>([&](auto I) {
+                constexpr int i = decltype(I)::value, t = i / TM, j = i % TM;
+                mfma16_asm(acc[t][j], wc[t], xc[j]);
+                constexpr int rd = interleave_slot(i, NMMA, NRD);   // the read (if any) that follows MFMA i
+                if constexpr (rd >= 0 && rd < TN) lds_read_frag<(rd < TN ? rd : 0) * 1024>(wnx[rd < TN ? rd : 0], wa);
+                else if constexpr (rd >= TN) lds_read_frag<(rd >= TN ? rd - TN : 0) * 1024>(xnx[rd >= TN ? rd - TN : 0], xa);
+            });
+            land(wnx, xnx);
         };
         for (int step = 0; step < nsteps; step += 2) {
             body(step, wfA, xfA, wfB, xfB);
             if (step + 1 < nsteps) body(step + 1, wfB, xfB, wfA, xfA);
         }
+        // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> VALU-read wait states by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[t][j]));
     } else
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step % NBUF;
@@ -823,12 +875,10 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             for (int t = 0; t < TN; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + ((wn * TN + t) * KTS + kk) * 1024 + lane * 16);
 #pragma unroll
             for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + ((wm * TM + j) * KTS + kk) * 1024 + lane * 16);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
     // epilogue with compile-time accumulator indices (a runtime-indexed acc[][] would be demoted to scratch)
@@ -861,19 +911,19 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     });
 }
 
-template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int PRIO = 0>
+template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, PRIO>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, PRIO>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
+    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
                        NTT, mblocks, nblocks);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
@@ -939,33 +989,29 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
-    // Tile choice from measurements on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles.txt): the 256x256x32
-    // 4-buffer tile wins whenever it yields about one workgroup per CU and K is long enough to amortise its
-    // prologue (950-980 TF/s on the prefill shapes); short-K (ViT, K=1152) and M~1024 problems that cannot
-    // fill 256 CUs with big tiles do better with 128(n)x64(m) (3 workgroups per CU) or 128x128 with two
-    // buffers (2 per CU).  UMV_GEMM_TILE=<256|128|129|130|64> overrides (tuning only).
+    // Tile choice from measurements on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles_auto.txt).  The 256x256x32
+    // 4-buffer tile with the interleaved schedule wins whenever it yields >= ~144 workgroups (885-1120 TF/s on the
+    // prefill / flow / ViT shapes); below that the 256(n) x 128(m) interleaved tile (M ~ 2048: 920-1020 TF/s), then
+    // 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
+    // UMV_GEMM_TILE=<256|266|258|268|129|130|270|64> overrides (tuning only).
     static int force = -1;
     if (force < 0) { const char* e = getenv("UMV_GEMM_TILE"); force = e ? atoi(e) : 0; }
     const long wg256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    int cfg;
     const long wg258 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
-    if (a.K < 2048) cfg = 64;
-    else if (wg256 >= 160) cfg = 256;      // e.g. guided flow M=3072: 168 tiles still beat smaller tiles (660-775 vs 500-610 TF/s)
-    else if (wg258 >= 200) cfg = 258;      // M~2048: 256(n) x 128(m), 8 waves
-    else if (wg128 >= 256) cfg = 129;
+    int cfg;
+    if (a.K < 1024) cfg = 64;              // short K: the 4-buffer prologue does not amortise
+    else if (wg256 >= 144) cfg = 266;
+    else if (wg258 >= 140) cfg = 268;
+    else if (wg128 >= 128) cfg = 270;
     else cfg = 64;
     if (force) cfg = force;
     if (cfg == 256) return launch_tiled<2, 4, 8, 4, 1, 4>(a, KT, NTT, s);      // 256x256x32, 4 buffers (128 KiB)
-    if (cfg == 128) return launch_tiled<2, 2, 4, 4, 2, 3>(a, KT, NTT, s);      // 128x128x64, 3 buffers (96 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
-    if (cfg == 260) return launch_tiled<2, 4, 8, 4, 2, 2>(a, KT, NTT, s);      // 256x256x64, 2 buffers (128 KiB)
-    if (cfg == 261) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, setprio around the MFMAs
-    if (cfg == 263) return launch_tiled<2, 4, 8, 4, 1, 4, 2>(a, KT, NTT, s);   // 256x256x32, 4 buffers, fragment double buffering
-    if (cfg == 262) return launch_tiled<2, 4, 8, 4, 1, 3>(a, KT, NTT, s);      // 256x256x32, 3 buffers (96 KiB)
-    if (cfg == 257) return launch_tiled<2, 4, 8, 2, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves, 4 buffers (96 KiB)
+    if (cfg == 266) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, MFMA / ds_read interleaved by hand
+    if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
+    if (cfg == 270) return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 128x128x32, 4 waves, 4 buffers (64 KiB, 2 WG/CU), interleaved
     if (cfg == 258) return launch_tiled<4, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves as 4x2 (96 KiB)
-    if (cfg == 259) return launch_tiled<2, 4, 4, 4, 1, 4>(a, KT, NTT, s);      // 128(n)x256(m)x32, 8 waves (96 KiB)
     return launch_tiled<2, 2, 4, 2, 2, 3>(a, KT, NTT, s);                      // 128(n) x 64(m) x 64, 3 buffers (72 KiB)
 }
