@@ -696,7 +696,7 @@ __device__ __forceinline__ void mfma16_asm(f32x4& c, const bf16x8& a, const bf16
 //     ds_read fragments of tile t, MFMAs
 // SCHED = 1: the same pipeline with the MFMAs of tile t and the ds_reads of tile t+1 interleaved by hand (see below).
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
-__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks) {
+__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;      // 1 KiB fragment tiles per k-step
@@ -717,8 +717,16 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
-    const int mblk = bid % mblocks;
-    const int nblk = bid / mblocks;
+    // Tile order inside the run: strips of gn n-blocks, m-block next, n-block within the strip fastest - the ~32 tiles an
+    // XCD works on at a time then cover (32 / gn) m-blocks x gn n-blocks and share both operands' k-slices in its L2
+    // (gn = 1 is plain m-fastest: every CU of the XCD streams its own x panel and only W is shared).
+    int mblk, nblk;
+    {
+        const int per = mblocks * gn, strip = bid / per, rem = bid - strip * per;
+        const int w = min(gn, nblocks - strip * gn);
+        mblk = rem / w;
+        nblk = strip * gn + rem % w;
+    }
     const int m0 = mblk * BM;
     const int nt_blk = nblk * (BN / 16);
     const int nt_base = nt_blk + wn * TN;
@@ -911,6 +919,12 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     });
 }
 
+static int raster_gn() {   // n-blocks per strip of the tile order; UMV_GEMM_RASTER overrides (tuning only)
+    static int gn = -1;
+    if (gn < 0) { const char* e = getenv("UMV_GEMM_RASTER"); gn = e ? atoi(e) : 4; if (gn < 1) gn = 1; }
+    return gn;
+}
+
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
@@ -924,7 +938,7 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     }
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
-                       NTT, mblocks, nblocks);
+                       NTT, mblocks, nblocks, raster_gn());
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }

@@ -127,7 +127,7 @@ extern "C" int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_
 
 // ----------------------------------------------------------------------------- the GEMM
 template <int WN, int WM, int TN, int TM, int NBUF>
-__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_args a, int KT, int NTT, int mblocks, int nblocks) {
+__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_args a, int KT, int NTT, int mblocks, int nblocks, int gn) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WPL = 2 * (BN / 16), XPL = 2 * (BM / 16);   // 1 KiB planes per k-step: W then x
@@ -146,7 +146,13 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
         const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
-    const int mblk = bid % mblocks, nblk = bid / mblocks;
+    int mblk, nblk;   // strips of gn n-blocks, n-block within the strip fastest (see gemm_tiled_kernel)
+    {
+        const int per = mblocks * gn, strip = bid / per, rem = bid - strip * per;
+        const int w = min(gn, nblocks - strip * gn);
+        mblk = rem / w;
+        nblk = strip * gn + rem % w;
+    }
     const int m0 = mblk * BM;
     const int nt_blk = nblk * (BN / 16);
     const int nt_base = nt_blk + wn * TN;
@@ -247,6 +253,12 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
     });
 }
 
+static int raster8_gn() {   // n-blocks per strip of the tile order; UMV_GEMM_RASTER overrides (tuning only)
+    static int gn = -1;
+    if (gn < 0) { const char* e = getenv("UMV_GEMM_RASTER"); gn = e ? atoi(e) : 4; if (gn < 1) gn = 1; }
+    return gn;
+}
+
 template <int WN, int WM, int TN, int TM, int NBUF>
 static int launch_tiled8(const umv_gemm8_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
@@ -260,7 +272,7 @@ static int launch_tiled8(const umv_gemm8_args& a, int KT, int NTT, hipStream_t s
     }
     const int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_tiled8_kernel<WN, WM, TN, TM, NBUF>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks,
-                       nblocks);
+                       nblocks, raster8_gn());
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
