@@ -126,6 +126,23 @@ extern "C" int umv_quantize_act_fp8(const uint16_t* x, int64_t ldx, const int32_
 }
 
 // ----------------------------------------------------------------------------- the GEMM
+// inline-asm building blocks of the hand-ordered k-step (free functions: clang rejects asm operands naming the enclosing
+// function's locals from inside a generic lambda)
+template <int OFF>
+__device__ __forceinline__ void lds_read16(u32x4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void mfma8_asm(f32x4& c, const i32x8& a, const i32x8& b, int one) {   // scales 2^0 on both operands
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(one));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {   // at most N of the LDS reads issued so far may still be in flight (in order)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ i32x8 frag8(const u32x4& lo, const u32x4& hi) {
+    return (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+}
+
 template <int WN, int WM, int TN, int TM, int NBUF>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_args a, int KT, int NTT, int mblocks, int nblocks, int gn) {
     constexpr int NW = WN * WM;
@@ -191,31 +208,56 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
 #pragma unroll
     for (int p = 0; p < NBUF - 1; ++p)
         if (p < KT) stage(p, p);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds8_ptr_t)smem;
+    const int one = 0x7f7f7f7f;    // E8M0 scale 2^0 in every byte
     for (int kt = 0; kt < KT; ++kt) {
         const int ahead = min(NBUF - 2, KT - 1 - kt);   // k-steps still allowed in flight behind step kt
         if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + NBUF - 1 < KT) stage(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
-        const char* wb = smem + (kt % NBUF) * BUF + lane * 16;
-        const char* xb = wb + WPL * 1024;
+        // Hand-ordered step.  Left to the compiler, every wave issues its 2 (TM + TN) ds_read_b128 right after the barrier
+        // and then its TN x TM MFMAs: the 8 waves' 192 KiB of reads (~1500 LDS cycles) and the ~2000 MFMA cycles per SIMD
+        // add up (MfmaUtil 47 %).  Here only the x fragments and the first two W fragments are requested up front; the W
+        // fragment of n-tile t+2 is requested between the MFMAs of n-tile t (three rotating register sets), and each wait
+        // lets the two newest reads stay in flight (LDS returns in order).
+        const uint32_t wb = lds0 + (kt % NBUF) * BUF + lane * 16 + wn * TN * 2048;
+        const uint32_t xb = lds0 + (kt % NBUF) * BUF + WPL * 1024 + lane * 16 + wm * TM * 2048;
+        u32x4 xlo[TM], xhi[TM], wlo[3], whi[3];
+        static_for<0, TM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            lds_read16<j * 2048>(xlo[j], xb);
+            lds_read16<j * 2048 + 1024>(xhi[j], xb);
+        });
+        static_for<0, (TN < 2 ? TN : 2)>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            lds_read16<t * 2048>(wlo[t], wb);
+            lds_read16<t * 2048 + 1024>(whi[t], wb);
+        });
         i32x8 xf[TM];
+        static_for<0, TN>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            if constexpr (t + 1 < TN) lds_wait<2>(); else lds_wait<0>();     // W fragment t (and the x fragments) have landed
+            if constexpr (t == 0) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(xb + (2 * (wm * TM + j)) * 1024);
-            const u32x4 hi = *reinterpret_cast<const u32x4*>(xb + (2 * (wm * TM + j) + 1) * 1024);
-            xf[j] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-        }
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(wb + (2 * (wn * TN + t)) * 1024);
-            const u32x4 hi = *reinterpret_cast<const u32x4*>(wb + (2 * (wn * TN + t) + 1) * 1024);
-            const i32x8 wf = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-                acc[t][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[t][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        }
+                for (int j = 0; j < TM; ++j) xf[j] = frag8(xlo[j], xhi[j]);
+            }
+            const i32x8 wf = frag8(wlo[t % 3], whi[t % 3]);
+            static_for<0, TM>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                mfma8_asm(acc[t][j], wf, xf[j], one);
+                if constexpr (j == (TM > 1 ? 1 : 0) && t + 2 < TN) {
+                    lds_read16<(t + 2) * 2048>(wlo[(t + 2) % 3], wb);
+                    lds_read16<(t + 2) * 2048 + 1024>(whi[(t + 2) % 3], wb);
+                }
+            });
+        });
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are opaque to the hazard recogniser: XDL write -> VALU read
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[t][j]));
     // epilogue: exact power-of-two scales, then the shared bf16 epilogue (bias / activation / SwiGLU / residual)
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
     const bool swiglu = (a.epilogue & UMV_EPI_SWIGLU) != 0;
