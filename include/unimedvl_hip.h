@@ -279,6 +279,11 @@ int umv_attn_decode_fused(const umv_attn_decode_args* a, umv_stream_t stream);
 /* decode bookkeeping kept on device so a whole step replays from a hipGraph:
  * slot[b]+=1, pos[b]+=1, kv_len[b]+=1 (the .tolist() bookkeeping of bagel.py:1266-1275,1303-1310) */
 int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int B, umv_stream_t stream);
+/* The same plus the token log of the loop, one launch at the end of a step: with s = step_idx[0],
+ * pred_ids[s][b] = ids[b] (the curr_tokens appended at bagel.py:1311-1312), in_ids[s+1][b] = ids[b] (what the next step is fed;
+ * in_ids[0] holds the start tokens, bagel.py:1263), counters += 1, step_idx[0] = s + 1.  in_ids / pred_ids are [max_len][B]. */
+int umv_decode_step_end(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const int64_t* ids, int64_t* in_ids,
+                        int64_t* pred_ids, int64_t* step_idx, int B, int max_len, umv_stream_t stream);
 
 /* Stream `bytes` at `ptr` through the cache hierarchy (no compute) so that they are resident in the
  * 256 MiB Infinity Cache for a later kernel; meant for a parallel stream / graph branch during the

@@ -114,6 +114,8 @@ _SIGS = {
     "umv_attn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "umv_attn_varlen": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "umv_decode_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "umv_decode_step_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_void_p]),
     "umv_prefetch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "umv_cfg_renorm_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]),

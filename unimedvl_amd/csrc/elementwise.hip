@@ -328,13 +328,27 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const bf16_t* __restrict__
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     const int nv = V / 8;
-    for (int c = threadIdx.x; c < nv; c += blockDim.x) {
-        bf16x8 v = ldg_frag(row + c * 8);
+    // one workgroup per row is latency bound (19 dependent round trips for V = 152064): request 8 chunks per thread at a
+    // time, then compare in index order (same result as the one-at-a-time loop)
+    constexpr int UA = 8;
+    for (int c0 = threadIdx.x; c0 < nv; c0 += blockDim.x * UA) {
+        bf16x8 v[UA];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float f = bf2f((bf16_t)v[j]);
-            int i = c * 8 + j;
-            if (f > best || (f == best && i < bidx) || (f != f && !(best != best))) { best = f; bidx = i; }
+        for (int u = 0; u < UA; ++u) {
+            const int c = c0 + u * blockDim.x;
+            v[u] = c < nv ? ldg_frag(row + c * 8) : zero_frag();
+        }
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int c = c0 + u * blockDim.x;
+            if (c < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = bf2f((bf16_t)v[u][j]);
+                    int i = c * 8 + j;
+                    if (f > best || (f == best && i < bidx) || (f != f && !(best != best))) { best = f; bidx = i; }
+                }
+            }
         }
     }
     for (int i = nv * 8 + threadIdx.x; i < V; i += blockDim.x) {
@@ -602,6 +616,30 @@ extern "C" int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* 
     UMV_CHECK(tok_slot && tok_pos && kv_len, UMV_ERR_ARG, "decode_advance: null pointer");
     if (B == 0) return UMV_OK;
     hipLaunchKernelGGL(decode_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tok_slot, tok_pos, kv_len, B);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// End of a decode step in ONE launch: log the token just predicted (pred_ids[s] = ids; in_ids[s + 1] = ids, the token the
+// next step is fed - bagel.py:1263,1311-1312), bump slot / position / kv_len and the step counter s.
+__global__ __launch_bounds__(256) void decode_step_end_kernel(int32_t* slot, int32_t* pos, int32_t* kv_len, const int64_t* ids,
+                                                              int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int B, int max_len) {
+    const int64_t s = step_idx[0];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int64_t id = ids[b];
+        if (s < max_len) pred_ids[s * B + b] = id;
+        if (s + 1 < max_len) in_ids[(s + 1) * B + b] = id;
+        slot[b] += 1; pos[b] += 1; kv_len[b] += 1;
+    }
+    __syncthreads();                 // everyone has read s
+    if (threadIdx.x == 0) step_idx[0] = s + 1;
+}
+extern "C" int umv_decode_step_end(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const int64_t* ids, int64_t* in_ids,
+                                   int64_t* pred_ids, int64_t* step_idx, int B, int max_len, umv_stream_t stream) {
+    UMV_CHECK(tok_slot && tok_pos && kv_len && ids && in_ids && pred_ids && step_idx && max_len > 0, UMV_ERR_ARG, "decode_step_end: bad args");
+    if (B == 0) return UMV_OK;
+    hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tok_slot, tok_pos, kv_len, ids, in_ids, pred_ids,
+                       step_idx, B, max_len);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }

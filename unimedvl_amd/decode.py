@@ -49,6 +49,8 @@ class DecodeSession:
         self.cu_q = torch.arange(B + 1, **i32)
         self.in_ids = torch.zeros((max_length, B), dtype=torch.int64, device=dev)    # token fed at each step
         self.pred_ids = torch.zeros((max_length, B), dtype=torch.int64, device=dev)  # token predicted at each step
+        if max_length > 0:
+            self.in_ids[0].copy_(self.ids)
         self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)
         max_kv = max(cache.lens) + max_length + 1
         # split the key range so that every wavefront walks ~2 blocks of 32 keys (latency bound otherwise)
@@ -116,8 +118,7 @@ class DecodeSession:
         nq, nkv, hd = cfg.heads, cfg.kv_heads, cfg.head_dim
         L = cfg.layers
         sq, so, sd = self.sk
-        self.in_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
-        ops.embed_gather(w.embed, self.ids, out=self.seq)
+        ops.embed_gather(w.embed, self.ids, out=self.seq)      # in_ids[step] already holds these tokens (decode_step_end)
         ops.rmsnorm(self.seq, w.und[0].in_norm, cfg.rms_eps, out=self.x)
         for l in range(L):
             lw = w.und[l]
@@ -159,9 +160,8 @@ class DecodeSession:
             ops.sample(self.logits, self.temperature, self.seed, step=self.step_idx, out=self.ids)
         else:
             ops.argmax(self.logits, out=self.ids)
-        self.pred_ids.index_copy_(0, self.step_idx, self.ids.unsqueeze(0))
-        ops.decode_advance(self.tok_slot, self.tok_pos, self.kv_len)
-        self.step_idx.add_(1)
+        # pred_ids[step] = in_ids[step + 1] = ids; slot / position / kv_len / step += 1: one launch
+        ops.decode_step_end(self.tok_slot, self.tok_pos, self.kv_len, self.ids, self.in_ids, self.pred_ids, self.step_idx)
 
     def _capture(self):
         # the captured step appends at slot = lens0 and bumps the counters; warm up on a side
@@ -203,6 +203,7 @@ class DecodeSession:
     def rewind_outputs(self):
         """Start writing in_ids / pred_ids at row 0 again (the caller has harvested the previous rows)."""
         self.step_idx.zero_()
+        self.in_ids[0].copy_(self.ids)      # the tokens the next step is fed (set_slot may have changed them)
         self.steps_done = 0
 
     def commit(self, steps=None):

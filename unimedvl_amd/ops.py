@@ -488,6 +488,17 @@ def decode_advance(tok_slot, tok_pos, kv_len):
     check(lib.umv_decode_advance(_p(tok_slot), _p(tok_pos), _p(kv_len), tok_slot.numel(), _stream()), "umv_decode_advance")
 
 
+def decode_step_end(tok_slot, tok_pos, kv_len, ids, in_ids, pred_ids, step_idx):
+    """pred_ids[s] = ids, in_ids[s + 1] = ids, counters += 1, s += 1 - the whole bookkeeping of a decode step in one launch."""
+    lib = _lib.load()
+    for t, name in ((ids, "ids"), (in_ids, "in_ids"), (pred_ids, "pred_ids"), (step_idx, "step_idx")):
+        _req(t, torch.int64, name)
+    if not (in_ids.is_contiguous() and pred_ids.is_contiguous() and in_ids.shape == pred_ids.shape and in_ids.shape[1] == ids.numel()):
+        raise _lib.UmvError("decode_step_end: in_ids / pred_ids must be contiguous [max_len, B]")
+    check(lib.umv_decode_step_end(_p(tok_slot), _p(tok_pos), _p(kv_len), _p(ids), _p(in_ids), _p(pred_ids), _p(step_idx),
+                                  ids.numel(), in_ids.shape[0], _stream()), "umv_decode_step_end")
+
+
 def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img, renorm_min, rtype, dt):
     lib = _lib.load()
     _req(x_t, torch.float32, "x_t")
