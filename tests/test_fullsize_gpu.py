@@ -1,0 +1,164 @@
+"""Size-independent properties at BASELINE.json's FULL dimensions (UniMedVL-14B dims, random N(0, 0.02^2) weights) - the
+CPU oracle cannot run these sizes in seconds, so the checks are relations the engine must satisfy with itself:
+
+  * decode == prefill: feeding the last prompt token through the decode step (weight-streaming GEMMs, split-K partials,
+    split-KV decode attention, HIP graph) must leave the same K / V in every layer, and then predict the same logits, as
+    prefilling the whole prompt at once (tiled MFMA GEMMs, prefill attention);
+  * batch independence: a sample decoded in a ragged batch of 8 gives bit-identical logits to the same sample decoded alone
+    (packed NaViT sequences have no cross-sample term: qwen2_navit.py:602-614);
+  * ViT segment permutation: encoding the images in another order permutes the outputs, bit for bit;
+  * HIP-graph replay == eager kernel sequence, bit for bit.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+class IdTok:
+    def __init__(self, table):
+        self.table = table
+
+    def encode(self, s):
+        return self.table[int(s)]
+
+
+@pytest.fixture(scope="module")
+def full():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.weights import random_getter
+    cfg = UniMedVLConfig()
+    dev = torch.device("cuda", 0)
+    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=False, visual_und=True)
+    ids = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
+    return model, cfg, ids
+
+
+def _prompts(lens, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(1000, 150000, (n,), generator=g).tolist() for n in lens]
+
+
+def _prefill(model, cfg, prompts, ids):
+    from unimedvl_amd.kvcache import NaiveCache
+    B = len(prompts)
+    cache = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], IdTok(prompts), ids)
+    cache = model.forward_cache_update_text(cache, **gi)
+    return cache, kvl, rope
+
+
+def test_decode_step_equals_prefill(full):
+    from copy import deepcopy
+    from unimedvl_amd.decode import DecodeSession
+    model, cfg, ids = full
+    prompts = _prompts([70, 33, 121, 64], 1)
+    B = len(prompts)
+    whole, kvl, rope = _prefill(model, cfg, prompts, ids)          # bos + prompt + eos
+    # the same sequences without their last token (eos): the wrapper appends `eos_token_id`, so hand it the last prompt token
+    short = []
+    for p in prompts:
+        c, k2, r2 = _prefill(model, cfg, [p[:-1]], dict(ids, eos_token_id=p[-1]))
+        short.append((c, k2[0], r2[0]))
+    for b, (c, k2, r2) in enumerate(short):
+        assert k2 == kvl[b] - 1
+        sess = DecodeSession(model.language_model, c, torch.tensor([ids["eos_token_id"]]), torch.tensor([r2]), 2, use_graph=True)
+        sess.step(1)
+        sess.commit()
+        assert c.lens == [kvl[b]]
+    worst_k = worst_v = 0.0
+    for l in (0, 1, cfg.layers // 2, cfg.layers - 1):
+        ka, va = whole.packed_keys(l).float(), whole.packed_values(l).float()       # [sum_len, kvh, hd]
+        off = 0
+        for b, (c, _, _) in enumerate(short):
+            kb, vb = c.packed_keys(l).float(), c.packed_values(l).float()
+            n = kvl[b]
+            for a_, b_, what in ((ka[off:off + n], kb, "K"), (va[off:off + n], vb, "V")):
+                d = (a_ - b_).abs()
+                scale = a_.abs().max().item()
+                rel_last, rel_all = d[-1].max().item() / scale, d.max().item() / scale
+                # measured: <= 0.03 at the last layer (bf16 roundings of two different kernel paths through 28 layers)
+                assert rel_all <= 0.08, f"layer {l} sample {b} {what}: {rel_all:.4f} of the value range"
+                assert d.mean().item() <= 0.01 * scale
+                if what == "K":
+                    worst_k = max(worst_k, rel_last)
+                else:
+                    worst_v = max(worst_v, rel_last)
+            off += n
+    print(f"decode-vs-prefill last-token K / V deviation: {worst_k:.4f} / {worst_v:.4f} of the value range")
+    # and the next-token logits from either cache
+    gi = model.prepare_start_tokens(kvl, rope, ids)
+    _, la = model.generate_text(past_key_values=deepcopy(whole), max_length=1, return_logits=True, **gi)
+    for b, (c, _, _) in enumerate(short):
+        gb = model.prepare_start_tokens([kvl[b]], [rope[b]], ids)
+        _, lb = model.generate_text(past_key_values=c, max_length=1, return_logits=True, **gb)
+        x, y = la[0, b].float(), lb[0, 0].float()
+        assert (x - y).abs().max() <= 0.05 * x.abs().max() + 0.05
+        top2 = x.topk(2).values
+        if top2[0] - top2[1] > 0.1 * x.abs().max():
+            assert int(x.argmax()) == int(y.argmax())
+
+
+def test_batch_independence_bit_exact(full):
+    from unimedvl_amd.decode import DecodeSession
+    model, cfg, ids = full
+    prompts = _prompts([70, 97, 121, 66, 83, 110, 75, 128], 2)     # > 64 rows each: the tiled GEMM prefills both ways
+    B = len(prompts)
+    cache, kvl, rope = _prefill(model, cfg, prompts, ids)
+    start = torch.full((B,), ids["bos_token_id"], dtype=torch.int64)
+    sess = DecodeSession(model.language_model, cache, start, torch.tensor(rope), 4, use_graph=False, nsplit=8)
+    batch_logits = []
+    for _ in range(3):
+        sess.step(1)
+        batch_logits.append(sess.logits.clone())
+    for b in (0, 3, 7):
+        c1, k1, r1 = _prefill(model, cfg, [prompts[b]], ids)
+        assert k1 == [kvl[b]] and r1 == [rope[b]]
+        s1 = DecodeSession(model.language_model, c1, start[:1], torch.tensor(r1), 4, use_graph=False, nsplit=8)
+        for s in range(3):
+            s1.step(1)
+            assert torch.equal(s1.logits[0], batch_logits[s][b]), f"sample {b} step {s}"
+        assert torch.equal(s1.pred_ids[:3, 0], sess.pred_ids[:3, b])
+
+
+def test_vit_segment_permutation(full):
+    import numpy as np
+    model, cfg, ids = full
+    rng = np.random.default_rng(5)
+    images = [torch.from_numpy(rng.uniform(-1, 1, size=(3, h, w)).astype("float32")) for h, w in ((448, 448), (224, 448), (448, 336))]
+
+    def encode(order):
+        imgs = [images[i] for i in order]
+        gi, _, _ = model.prepare_vit_images([0] * 3, [0] * 3, imgs, lambda x: x, ids)
+        out = model.encode_vit(gi["packed_vit_tokens"].to(model.device), gi["packed_vit_position_ids"].to(model.device), gi["vit_token_seqlens"])
+        return list(torch.split(out, gi["vit_token_seqlens"].tolist()))
+    a = encode([0, 1, 2])
+    b = encode([2, 0, 1])
+    assert a[0].shape[0] == 1024 and a[1].shape[0] == 512 and a[2].shape[0] == 768
+    assert torch.equal(a[2], b[0]) and torch.equal(a[0], b[1]) and torch.equal(a[1], b[2])
+    assert torch.isfinite(a[0].float()).all() and a[0].float().abs().max() > 0
+
+
+def test_graph_replay_equals_eager(full):
+    from copy import deepcopy
+    from unimedvl_amd.decode import DecodeSession
+    model, cfg, ids = full
+    prompts = _prompts([40, 12, 77, 5, 64, 33, 90, 21], 3)
+    B = len(prompts)
+    cache, kvl, rope = _prefill(model, cfg, prompts, ids)
+    start = torch.full((B,), ids["bos_token_id"], dtype=torch.int64)
+    runs = []
+    for use_graph in (False, True):
+        sess = DecodeSession(model.language_model, deepcopy(cache), start, torch.tensor(rope), 5, use_graph=use_graph)
+        logits = []
+        for _ in range(4):
+            sess.step(1)
+            logits.append(sess.logits.clone())
+        runs.append((sess.pred_ids[:4].clone(), sess.in_ids[:5].clone(), torch.stack(logits)))
+    for x, y in zip(*runs):
+        assert torch.equal(x, y)
+    assert torch.equal(runs[0][1][0].cpu(), start) and torch.equal(runs[0][1][1:5], runs[0][0][:4])   # in_ids = start, then the predictions
