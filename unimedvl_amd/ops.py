@@ -12,7 +12,13 @@ from ._lib import (EPI_BIAS, EPI_GELU_TANH, EPI_OUT_F32, EPI_RESIDUAL, EPI_SILU,
 BF16 = torch.bfloat16
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (every op launches there)."""
+    if _raw_stream is not None:       # ~0.3 us instead of ~3 us for building a torch.cuda.Stream object per launch
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -20,8 +20,7 @@ from .config import UniMedVLConfig
 BF16 = torch.bfloat16
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = ops._stream
 
 
 class _Conv:
