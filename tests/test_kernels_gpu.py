@@ -311,3 +311,32 @@ def test_f2bf_exhaustive(ops):
         nan = torch.isnan(x)
         assert torch.equal(got[~nan], ref[~nan]), f"chunk {c}"
         assert torch.isnan(got.view(torch.bfloat16)[nan].float()).all()
+
+
+@pytest.mark.parametrize("nq,nkv,hd", [(16, 16, 72), (1, 1, 512), (4, 2, 128), (3, 3, 40), (2, 1, 20)])
+def test_qkv_split_without_norm(ops, nq, nkv, hd):
+    """No-norm split (ViT / VAE attention, siglip_navit.py:222-231, autoencoder.py:51-60): q rows, K rows and V^T columns are
+    plain copies.  The 8-token tile path must handle aligned runs, a run starting at a slot that is not a multiple of 8,
+    a segment change inside a group of 8 and a ragged tail; hd = 20 (not a multiple of 8) takes the element kernel."""
+    g = torch.Generator().manual_seed(nq * 100 + hd)
+    lens, starts = [24, 13, 16, 5], [0, 3, 8, 40]          # tokens per segment and the slot their run starts at
+    T, cap = sum(lens), 64
+    seg = torch.cat([torch.full((n,), s, dtype=torch.int32) for s, n in enumerate(lens)])
+    slot = torch.cat([torch.arange(st, st + n, dtype=torch.int32) for st, n in zip(starts, lens)])
+    N = (nq + 2 * nkv) * hd
+    qkv = torch.randn(T, N, generator=g).to(BF16)
+    slab = ops.KVSlab(len(lens), nkv, cap, hd, "cuda")
+    slab.k.fill_(7.0)
+    slab.vt.fill_(7.0)
+    q_out = torch.zeros((T, nq, hd), dtype=BF16, device="cuda")
+    ops.qkv_post(qkv.cuda(), q_out, slab, seg.cuda(), slot.cuda(), None, nq, nkv, hd)
+    assert torch.equal(q_out.cpu(), qkv[:, :nq * hd].view(T, nq, hd))
+    k_ref = torch.full((len(lens), nkv, cap, hd), 7.0, dtype=BF16)
+    v_ref = torch.full((len(lens), nkv, hd, cap), 7.0, dtype=BF16)
+    k = qkv[:, nq * hd:(nq + nkv) * hd].view(T, nkv, hd)
+    v = qkv[:, (nq + nkv) * hd:].view(T, nkv, hd)
+    for t in range(T):
+        k_ref[seg[t], :, slot[t]] = k[t]
+        v_ref[seg[t], :, :, slot[t]] = v[t]
+    assert torch.equal(slab.k.cpu(), k_ref)          # untouched slots keep their content
+    assert torch.equal(slab.vt.cpu(), v_ref)
