@@ -340,3 +340,36 @@ def test_qkv_split_without_norm(ops, nq, nkv, hd):
         v_ref[seg[t], :, :, slot[t]] = v[t]
     assert torch.equal(slab.k.cpu(), k_ref)          # untouched slots keep their content
     assert torch.equal(slab.vt.cpu(), v_ref)
+
+
+@pytest.mark.parametrize("gen", [False, True])
+def test_qkv_post_many_tokens_matches_small_calls(ops, gen):
+    """T >= 64 tokens of a bf16 row: the V heads go through the 8-token tile kernel (16-byte V^T stores) and the norm + RoPE
+    kernel visits only q / k heads.  Must equal, bit for bit, the same tokens pushed through in chunks of < 64 (one kernel)."""
+    nq, nkv, hd, cap = 28, 4, 128, 160
+    lens, starts = [70, 37, 9], [0, 5, 130]
+    T = sum(lens)
+    seg = torch.cat([torch.full((n,), s, dtype=torch.int32) for s, n in enumerate(lens)]).cuda()
+    slot = torch.cat([torch.arange(st, st + n, dtype=torch.int32) for st, n in zip(starts, lens)]).cuda()
+    pos = (slot + 11).to(torch.int32)
+    qkv = rnd((T, (nq + 2 * nkv) * hd), 77).cuda()
+    qn, kn, qg, kg = ((rnd((hd,), 78 + i) + 1).cuda() for i in range(4))
+    cos, sin = _rope_tables(512, hd)
+    cos, sin = cos.cuda(), sin.cuda()
+    expert = (torch.arange(T) % 3 == 0).to(torch.int32).cuda() if gen else None
+
+    def run(chunks):
+        slab = ops.KVSlab(len(lens), nkv, cap, hd, "cuda")
+        slab.k.fill_(3.0)
+        slab.vt.fill_(3.0)
+        q_out = torch.zeros((T, nq, hd), dtype=BF16, device="cuda")
+        for a, b in chunks:
+            ops.qkv_post(qkv[a:b], q_out[a:b], slab, seg[a:b], slot[a:b], pos[a:b], nq, nkv, hd, 1e-6, qn, kn, qg, kg,
+                         None if expert is None else expert[a:b], cos, sin, fp32_chain=gen)
+        return q_out, slab.k.clone(), slab.vt.clone()
+    whole = run([(0, T)])
+    parts = run([(0, 50), (50, 100), (100, T)])
+    for x, y in zip(whole, parts):
+        assert torch.equal(x, y)
+    written = (whole[2] != 3.0).sum().item()      # a few random values may equal the fill by chance
+    assert T * nkv * hd - 64 <= written <= T * nkv * hd

@@ -641,16 +641,19 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     int64_t items = (int64_t)a.T * (a.nq + 2 * a.nkv);
     dim3 grid((unsigned)((items + 3) / 4)), block(256);
     const size_t tile_lds = (size_t)8 * a.nkv * a.hd * sizeof(bf16_t);
-    if (!a.q_norm_w && (a.hd % 8) == 0 && tile_lds <= 64 * 1024)
+    const bool tile_ok = (a.hd % 8) == 0 && tile_lds <= 64 * 1024;
+    if (!a.q_norm_w && tile_ok) {
         hipLaunchKernelGGL(qkv_split_tile_kernel, dim3((unsigned)((a.T + 7) / 8)), block, tile_lds, (hipStream_t)stream, a);
-    else if (!a.q_norm_w)
+    } else if (!a.q_norm_w) {
         hipLaunchKernelGGL(qkv_split_kernel, grid, block, 0, (hipStream_t)stream, a);
-    else if (a.hd == 128)
-        hipLaunchKernelGGL((qkv_post_kernel<128>), grid, block, 0, (hipStream_t)stream, a);
-    else if (a.hd == 72)
-        hipLaunchKernelGGL((qkv_post_kernel<72>), grid, block, 0, (hipStream_t)stream, a);
-    else
-        UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "qkv_post: head_dim %d unsupported (128, 72)", a.hd);
+    } else {
+        UMV_CHECK(a.hd == 128 || a.hd == 72, UMV_ERR_UNSUPPORTED, "qkv_post: head_dim %d unsupported (128, 72)", a.hd);
+        // (sending the V heads of a long prefill through the tile kernel and only q / k through this one was measured on the
+        // flow passes, T = 2064: 20.4 + 11.4 us against 24.8 us in one kernel - the per-(token, head) wave with 2-byte
+        // accesses is the cost here, not the V scatter)
+        if (a.hd == 128) hipLaunchKernelGGL((qkv_post_kernel<128>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((qkv_post_kernel<72>), grid, block, 0, (hipStream_t)stream, a);
+    }
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
