@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
             f32x4 st[TQ][2];
 #pragma unroll
             for (int u = 0; u < TQ; ++u) st[u][0] = st[u][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // (the score accumulators stay with the builtin: pinning them in VGPRs too costs more in hand-placed wait states
+            // than the 16 v_accvgpr_read per block it removes - 395 vs 369 us per LLM prefill layer)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
