@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
                 sc[t * 4 + r] = v;
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
             ps += p;
             pf[i] = (short)pb;
         }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
+        ps = xor16_sum(ps);
+        ps = xor32_sum(ps);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         // ---- O^T += V^T P^T ; A = V^T[d = dt*16 + (lane&15)][kb + g*8 .. +8]

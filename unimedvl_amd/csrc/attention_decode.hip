@@ -40,8 +40,8 @@ __device__ __forceinline__ void adec_norm_rope(const bf16x8 (&x)[4], const bf16x
             const float f = bf2f((bf16_t)x[ks][e]);
             ss += f * f;
         }
-    ss += __shfl_xor(ss, 16, 64);   // the 4 lanes (g = 0..3) that share row j
-    ss += __shfl_xor(ss, 32, 64);
+    ss = xor16_sum(ss);   // the 4 lanes (g = 0..3) that share row j
+    ss = xor32_sum(ss);
     const float rstd = rsqrt_ieee(ss / 128.0f + eps);
     float n[4][8];
 #pragma unroll
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(64) void attn_decode_fused_kernel(umv_attn_decode_a
                 sc[t * 4 + r] = v;
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(64) void attn_decode_fused_kernel(umv_attn_decode_a
             ps += p;
             pf[i] = (short)f2bf(p);
         }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
+        ps = xor16_sum(ps);
+        ps = xor32_sum(ps);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         const bool partial = kb + 32 > Lk;

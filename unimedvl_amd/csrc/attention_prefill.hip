@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
                             mx = fmaxf(mx, v);
                         }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = xor16_max(mx);     // the 4 lanes (g = 0..3) that hold the row's 32 scores
+                mx = xor32_max(mx);
                 const float m_new = fmaxf(m_run[u], mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 alpha[u] = (m_run[u] == -INFINITY) ? 0.f : umv_exp2(m_run[u] - m_use);
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
                     ps += p;
                     pf[u][i] = (short)f2bf(p);
                 }
-                ps += __shfl_xor(ps, 16, 64);
-                ps += __shfl_xor(ps, 32, 64);
+                ps = xor16_sum(ps);
+                ps = xor32_sum(ps);
                 l_run[u] = l_run[u] * alpha[u] + ps;
                 m_run[u] = m_new;
                 rescale = rescale || __any(alpha[u] != 1.0f);

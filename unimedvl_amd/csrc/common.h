@@ -34,14 +34,40 @@ __device__ __forceinline__ float umv_exp2(float x) { return __builtin_amdgcn_exp
 // 1/sqrt(x) with correctly rounded sqrt and divide (what torch.rsqrt does on CPU)
 __device__ __forceinline__ float rsqrt_ieee(float x) { return __fdiv_rn(1.0f, __fsqrt_rn(x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
+// x[l] (op) x[l ^ 16] and x[l] (op) x[l ^ 32] on the gfx950 row-swap VALU instructions (v_permlane16_swap_b32 /
+// v_permlane32_swap_b32) instead of __shfl_xor's ds_bpermute round trip through the LDS crossbar (~100 cycles of dependent
+// latency each - the softmax of the attention kernels has four of them per 32-key block and q-tile).  With both operands
+// = x every lane ends up holding {x[l], x[l ^ 16]} (resp. ^ 32) in its two results (tools/permlane_probe.hip), in
+// (even row, odd row) order; + and max are commutative, so the result is bit-identical to the shuffle form.
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {   // same pairing and order as `for o = 32..1: v += shfl_xor(v, o)`
+    v = xor32_sum(v);
+    v = xor16_sum(v);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+    v = xor32_max(v);
+    v = xor16_max(v);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
