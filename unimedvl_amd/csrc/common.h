@@ -56,18 +56,38 @@ __device__ __forceinline__ float xor32_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// x[l ^ 8], x[l ^ 4], x[l ^ 2], x[l ^ 1] inside a 16-lane row as DPP moves (the compiler folds them into the consuming
+// VALU op) instead of ds_bpermute: row_ror:8; row_shl:4 into the lanes with bit 2 clear + row_shr:4 into the others
+// (bank masks 0b0101 / 0b1010); quad_perm [2,3,0,1] and [1,0,3,2].
+template <int O>
+__device__ __forceinline__ float row_xor(float v) {
+    const int x = __float_as_int(v);
+    int r;
+    if constexpr (O == 8) r = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);
+    else if constexpr (O == 4) {
+        r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
+        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);
+    } else if constexpr (O == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
+    else r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
+    return __int_as_float(r);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {   // same pairing and order as `for o = 32..1: v += shfl_xor(v, o)`
     v = xor32_sum(v);
     v = xor16_sum(v);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += row_xor<8>(v);
+    v += row_xor<4>(v);
+    v += row_xor<2>(v);
+    v += row_xor<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = xor32_max(v);
     v = xor16_max(v);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, row_xor<8>(v));
+    v = fmaxf(v, row_xor<4>(v));
+    v = fmaxf(v, row_xor<2>(v));
+    v = fmaxf(v, row_xor<1>(v));
     return v;
 }
 
