@@ -22,7 +22,9 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 // 32-key blocks per LDS stage.  hd 128: one (2 x 16 KiB per workgroup, so three workgroups share a CU - the kernel's 156
 // VGPRs allow three waves per SIMD - and hide each other's softmax latency chains: 354 -> 341 us per LLM prefill layer);
 // hd 72: two (fewer barriers win there: 120 vs 124 us per ViT layer).  Same block order either way: bit-identical.
-constexpr int ATTN_PREFILL_NB(int hd) { return hd > 96 ? 1 : 2; }
+// Only with TQ = 2, i.e. on large grids: a small grid (the 34-token text prefill: 128 workgroups, TQ = 1) has no
+// co-resident workgroup to hide the one-stage prefetch distance behind, and 32-key stages cost it 47 -> 126 us per layer.
+constexpr int ATTN_PREFILL_NB(int hd, int tq) { return (hd > 96 && tq == 2) ? 1 : 2; }
 
 __device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // keep the first nvalid (0..8) elements
     bf16x8 o;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
     constexpr int KS = (HD + 31) / 32;
     constexpr int DT = (HD + 15) / 16;
     constexpr int FK = 2 * KS, FB = FK + DT;   // fragments (1 KiB each) per 32-key block: K then V^T
-    constexpr int NB = ATTN_PREFILL_NB(HD);    // 32-key blocks per stage
+    constexpr int NB = ATTN_PREFILL_NB(HD, TQ);    // 32-key blocks per stage
     constexpr int STAGE = NB * FB * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages
     const int lane = threadIdx.x & 63;
@@ -251,7 +253,7 @@ bool umv_attn_prefill_enabled() {
 template <int HD, int TQ>
 static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
     constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
-    constexpr int lds = 2 * ATTN_PREFILL_NB(HD) * (2 * KS + DT) * 1024;
+    constexpr int lds = 2 * ATTN_PREFILL_NB(HD, TQ) * (2 * KS + DT) * 1024;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
