@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
         }
 #pragma unroll
     for (int sidx = 0; sidx < MAXS; ++sidx) {
-        const float w = __shfl(wgt, sidx, 64);
+        const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), sidx));   // v_readlane, not ds_bpermute
 #pragma unroll
         for (int i = 0; i < PER; ++i) acc[i] += w * vals[sidx][i];
     }
