@@ -133,7 +133,9 @@ extern "C" int umv_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, const uint
 // Consumer of a split-K decode GEMM (umv_gemm_args.k_splits): finishes o_proj / down_proj and runs the next RMSNorm in
 // one launch.   seq[t,:] = bf16( bf16(sum_s P[s][t,:]) + seq[t,:] )   (the GEMM output rounding, then the residual add:
 // qwen2_navit.py:873-874,897-898), splits added in order 0..S-1;   out[t,:] = w * bf16(seq * rstd)   (modeling_qwen2.py:89-94)
-template <int MAXV>
+// NS > 0: that many splits, known at compile time so that all their loads are requested before the first add (a run-time
+// loop costs one L2 round trip per split on this latency-bound kernel); NS = 0: S of them at run time.
+template <int MAXV, int NS>
 __global__ __launch_bounds__(256) void residual_rmsnorm_kernel(const float* __restrict__ P, int S, int64_t sstride, int64_t ldp,
                                                                bf16_t* __restrict__ seq, const bf16_t* __restrict__ w,
                                                                bf16_t* __restrict__ out, int H, float eps) {
@@ -152,6 +154,19 @@ __global__ __launch_bounds__(256) void residual_rmsnorm_kernel(const float* __re
             ww[i] = ldg_frag(w + c * 8);
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const float* p = P + (int64_t)row * ldp + c * 8;
+            if constexpr (NS > 0) {
+                f32x4 a0[NS], a1[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    a0[s] = *reinterpret_cast<const f32x4*>(p + s * sstride);
+                    a1[s] = *reinterpret_cast<const f32x4*>(p + s * sstride + 4);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    acc[0] += a0[s].x; acc[1] += a0[s].y; acc[2] += a0[s].z; acc[3] += a0[s].w;
+                    acc[4] += a1[s].x; acc[5] += a1[s].y; acc[6] += a1[s].z; acc[7] += a1[s].w;
+                }
+            } else
             for (int s = 0; s < S; ++s) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + s * sstride);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + s * sstride + 4);
@@ -192,10 +207,19 @@ extern "C" int umv_residual_rmsnorm_bf16(const float* partials, int n_splits, in
               "residual_rmsnorm: H=%d (multiple of 8, <= 8192) / ldp / split_stride (multiples of 4) unsupported", H);
     if (T == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (H <= 256 * 8 * 2)
-        hipLaunchKernelGGL((residual_rmsnorm_kernel<2>), dim3(T), dim3(256), 0, s, partials, n_splits, split_stride, ldp, seq, w, out, H, eps);
-    else
-        hipLaunchKernelGGL((residual_rmsnorm_kernel<4>), dim3(T), dim3(256), 0, s, partials, n_splits, split_stride, ldp, seq, w, out, H, eps);
+#define UMV_RRN_LAUNCH(MAXV, NS) \
+    hipLaunchKernelGGL((residual_rmsnorm_kernel<MAXV, NS>), dim3(T), dim3(256), 0, s, partials, n_splits, split_stride, ldp, seq, w, out, H, eps)
+    if (H <= 256 * 8 * 2) {
+        switch (n_splits) {
+            case 2: UMV_RRN_LAUNCH(2, 2); break;
+            case 3: UMV_RRN_LAUNCH(2, 3); break;
+            case 4: UMV_RRN_LAUNCH(2, 4); break;
+            default: UMV_RRN_LAUNCH(2, 0); break;
+        }
+    } else {
+        UMV_RRN_LAUNCH(4, 0);
+    }
+#undef UMV_RRN_LAUNCH
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -504,8 +528,23 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
         if (a.qkv_partials) {   // split-K QKV GEMM: x = bf16(sum_s P[s] + bias), the rounding of the GEMM epilogue it replaces
             const int64_t col = (int64_t)h * HD + lane;
             const float* p = a.qkv_partials + (int64_t)t * nheads * HD + col;
-            for (int s = 0; s < a.n_splits; ++s) { x1 += p[s * a.split_stride]; x2 += p[s * a.split_stride + HALF]; }
-            if (a.qkv_bias) { x1 += bf2f(a.qkv_bias[col]); x2 += bf2f(a.qkv_bias[col + HALF]); }
+            if (a.n_splits <= 4) {   // the usual case: request every split (and the bias) before the first add - one round trip
+                float t1[4], t2[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ss = s < a.n_splits ? s : 0;     // clamped address, masked below: no branch around the loads
+                    t1[s] = p[ss * a.split_stride];
+                    t2[s] = p[ss * a.split_stride + HALF];
+                }
+                const float b1 = a.qkv_bias ? bf2f(a.qkv_bias[col]) : 0.f, b2 = a.qkv_bias ? bf2f(a.qkv_bias[col + HALF]) : 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < a.n_splits) { x1 += t1[s]; x2 += t2[s]; }
+                if (a.qkv_bias) { x1 += b1; x2 += b2; }
+            } else {
+                for (int s = 0; s < a.n_splits; ++s) { x1 += p[s * a.split_stride]; x2 += p[s * a.split_stride + HALF]; }
+                if (a.qkv_bias) { x1 += bf2f(a.qkv_bias[col]); x2 += bf2f(a.qkv_bias[col + HALF]); }
+            }
             x1 = rbf(x1);
             x2 = rbf(x2);
         } else {
