@@ -523,6 +523,21 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
     const int seg = a.tok_seg[t], slot = a.tok_slot[t];
     const bool is_q = h < a.nq, is_k = !is_q && h < a.nq + a.nkv;
     const bool act = lane < HALF;  // HD=128: all 64 lanes; HD=72: 36 lanes
+    // The kernel is one dependent chain of memory round trips at decode sizes, so everything that does not depend on the
+    // row itself is requested first: position -> cos / sin, expert flag -> norm weight (this kernel always has the norms).
+    const bool is_v = !is_q && !is_k;
+    const int pos = a.tok_pos[t];
+    const bf16_t* nw = is_q ? a.q_norm_w : a.k_norm_w;
+    if (a.expert && a.expert[t]) nw = is_q ? a.q_norm_w_gen : a.k_norm_w_gen;
+    float c1 = 0.f, s1 = 0.f, c2 = 0.f, s2 = 0.f, w1 = 0.f, w2 = 0.f;
+    if (act && !is_v) {
+        c1 = bf2f(a.cos_tab[(int64_t)pos * HD + lane]);
+        s1 = bf2f(a.sin_tab[(int64_t)pos * HD + lane]);
+        c2 = bf2f(a.cos_tab[(int64_t)pos * HD + lane + HALF]);
+        s2 = bf2f(a.sin_tab[(int64_t)pos * HD + lane + HALF]);
+        w1 = bf2f(nw[lane]);
+        w2 = bf2f(nw[lane + HALF]);
+    }
     float x1 = 0.f, x2 = 0.f;
     if (act) {
         if (a.qkv_partials) {   // split-K QKV GEMM: x = bf16(sum_s P[s] + bias), the rounding of the GEMM epilogue it replaces
@@ -562,22 +577,10 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
         return;
     }
     float o1 = x1, o2 = x2;
-    const bf16_t* nw = is_q ? a.q_norm_w : a.k_norm_w;
-    if (nw) {
+    {
         const bool gen = a.fp32_chain != 0;
-        if (a.expert && a.expert[t]) nw = is_q ? a.q_norm_w_gen : a.k_norm_w_gen;
         float ss = wave_sum(x1 * x1 + x2 * x2);
         const float rstd = rsqrt_ieee(ss / (float)HD + a.eps);
-        const int pos = a.tok_pos[t];
-        float c1 = 0.f, s1 = 0.f, c2 = 0.f, s2 = 0.f, w1 = 0.f, w2 = 0.f;
-        if (act) {
-            c1 = bf2f(a.cos_tab[(int64_t)pos * HD + lane]);
-            s1 = bf2f(a.sin_tab[(int64_t)pos * HD + lane]);
-            c2 = bf2f(a.cos_tab[(int64_t)pos * HD + lane + HALF]);
-            s2 = bf2f(a.sin_tab[(int64_t)pos * HD + lane + HALF]);
-            w1 = bf2f(nw[lane]);
-            w2 = bf2f(nw[lane + HALF]);
-        }
         if (!gen) {
             float n1 = rbf(w1 * rbf(x1 * rstd));
             float n2 = rbf(w2 * rbf(x2 * rstd));
