@@ -222,11 +222,15 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
 // fully unrolled loads (the kernel is pure latency otherwise).
 template <int HD, int MAXS>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out,
-                                                           const int32_t* __restrict__ cu_q, int nseg, int nq, int nsplit) {
+                                                           const int32_t* __restrict__ cu_q, int nseg, int nq, int nsplit,
+                                                           int64_t rows_static) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (tok*nq + head)
-    if (row >= (int64_t)cu_q[nseg] * nq) return;
-    const float* base = ws + row * nsplit * (HD + 4);
+    // The exact row count lives on the device (cu_q[nseg]); waiting for it before anything else would add a memory round
+    // trip to a kernel that is nothing but latency.  The workspace covers the static bound, so the loads below are safe for
+    // any row of the grid (clamped), and only the store at the end depends on the count.
+    const int64_t valid_rows = (int64_t)cu_q[nseg] * nq;
+    const float* base = ws + min(row, rows_static - 1) * nsplit * (HD + 4);
     float m = -INFINITY, l = 0.f;
     if (lane < nsplit) {
         m = base[lane * (HD + 4) + HD];
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
         for (int i = 0; i < PER; ++i) acc[i] += w * vals[sidx][i];
     }
     const float inv = L > 0.f ? 1.0f / L : 0.f;
+    if (row >= valid_rows) return;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int d = i * 64 + lane;
@@ -301,9 +306,9 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
 int umv_attn_combine_launch(const float* ws, uint16_t* out, const int32_t* cu_q, int nseg, int nq, int hd, int nsplit, int64_t rows,
                             hipStream_t s) {
     if (hd == 128)
-        hipLaunchKernelGGL((attn_combine_kernel<128, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, out, cu_q, nseg, nq, nsplit);
+        hipLaunchKernelGGL((attn_combine_kernel<128, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, out, cu_q, nseg, nq, nsplit, rows);
     else
-        hipLaunchKernelGGL((attn_combine_kernel<72, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, out, cu_q, nseg, nq, nsplit);
+        hipLaunchKernelGGL((attn_combine_kernel<72, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, out, cu_q, nseg, nq, nsplit, rows);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
