@@ -77,7 +77,9 @@ class DecodeSession:
         #   o_proj 8.7 either way (its exact-partition image without a split keeps the residual add in the GEMM).
         sk = os.environ.get("UMV_DECODE_SPLITK", "auto")
         if sk == "auto":
-            sk = "0" if B > 64 else ("3,4,4" if (B > 8 or w.fp8) else "3,1,4")
+            # (B <= 8 bf16: 3,4,4 3.151 ms vs 3,1,4 3.161 - a wash, so one setting for every batch and weight type; it also
+            # makes the exact-partition copy of the o_proj weights unnecessary)
+            sk = "0" if B > 64 else "3,4,4"
         self.sk = (1, 1, 1) if sk in ("0", "") else tuple(max(1, int(v)) for v in sk.split(","))
         if len(self.sk) != 3 or any(v > 64 for v in self.sk):
             raise ValueError(f"UMV_DECODE_SPLITK={sk!r}: expected 'q,o,d' with 1 <= splits <= 64")
