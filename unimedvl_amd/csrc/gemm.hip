@@ -983,6 +983,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (a.k_splits > 1) {
         // split-K decode GEMM: 4 n-tiles per workgroup share every x fragment (x re-reads from L2 drop 4x against the
         // one-tile workgroups), the K range is cut k_splits ways to keep >= 256 workgroups, partial sums go to fp32
+        // (two n-tiles per workgroup at M <= 8 - twice the workgroups, 216-224 is less than one per CU - measured 3.199 vs
+        // 3.176 ms per step: no)
         if (a.M <= 16) return launch_skinny<1, 4, 2, true, 0>(a, KT, NTT, s);
         if (a.M <= 32) return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
         return launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
