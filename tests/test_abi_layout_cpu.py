@@ -1,0 +1,64 @@
+"""The ctypes mirrors in unimedvl_amd/_lib.py must have exactly the layout a C compiler gives the structs of
+include/unimedvl_hip.h (sizes and every field offset): the header is compiled with gcc into a tiny program that prints
+them.  Guards the C ABI against drift when a field is added on one side only."""
+import ctypes
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "unimedvl_hip.h")
+
+PAIRS = {   # C struct -> ctypes class name in unimedvl_amd._lib
+    "umv_gemm_args": "GemmArgs",
+    "umv_qkv_post_args": "QkvPostArgs",
+    "umv_attn_args": "AttnArgs",
+    "umv_attn_decode_args": "AttnDecodeArgs",
+    "umv_gemm8_args": "Gemm8Args",
+    "umv_decode_layout": "DecodeLayout",
+}
+
+
+def _c_fields(struct):
+    """Field names of `typedef struct { ... } <struct>;` in declaration order (comments stripped, `a, b;` lists split)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    m = re.search(r"typedef struct\s*\{([^{}]*)\}\s*" + struct + r"\s*;", src)
+    assert m, struct
+    names = []
+    for decl in m.group(1).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z_0-9]*", part)[-1])
+    return names
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_ctypes_structs_match_the_header(tmp_path):
+    from unimedvl_amd import _lib
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cs in PAIRS:
+        lines.append(f'  printf("{cs} size %zu\\n", sizeof({cs}));')
+        for f in _c_fields(cs):
+            lines.append(f'  printf("{cs} {f} %zu\\n", offsetof({cs}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True)
+    c = {}
+    for ln in out.splitlines():
+        s, f, v = ln.split()
+        c.setdefault(s, {})[f] = int(v)
+    for cs, pyname in PAIRS.items():
+        cls = getattr(_lib, pyname)
+        assert ctypes.sizeof(cls) == c[cs]["size"], f"{cs}: sizeof {c[cs]['size']} in C, {ctypes.sizeof(cls)} in ctypes"
+        py_fields = [n for n, _ in cls._fields_]
+        assert py_fields == _c_fields(cs), f"{cs}: field order differs\n C : {_c_fields(cs)}\n py: {py_fields}"
+        for n in py_fields:
+            assert getattr(cls, n).offset == c[cs][n], f"{cs}.{n}: offset {c[cs][n]} in C, {getattr(cls, n).offset} in ctypes"
