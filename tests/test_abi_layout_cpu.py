@@ -62,3 +62,28 @@ def test_ctypes_structs_match_the_header(tmp_path):
         assert py_fields == _c_fields(cs), f"{cs}: field order differs\n C : {_c_fields(cs)}\n py: {py_fields}"
         for n in py_fields:
             assert getattr(cls, n).offset == c[cs][n], f"{cs}.{n}: offset {c[cs][n]} in C, {getattr(cls, n).offset} in ctypes"
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every function the header declares is bound in _lib._SIGS with the same number of parameters, pointer parameters as
+    pointers / void*, 64-bit integers as 64-bit, floats as floats."""
+    from unimedvl_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    src = re.sub(r"typedef struct\s*\{[^{}]*\}\s*\w+\s*;", "", src)
+    decls = re.findall(r"\b(?:int|size_t|const char\s*\*)\s+(umv_\w+)\s*\(([^()]*)\)\s*;", src)
+    assert len(decls) >= 40
+    for name, params in decls:
+        assert name in _lib._SIGS, f"{name} is declared in the header but not bound"
+        plist = [p.strip() for p in params.split(",")] if params.strip() not in ("", "void") else []
+        argtypes = _lib._SIGS[name][1]
+        assert len(argtypes) == len(plist), f"{name}: {len(plist)} parameters in the header, {len(argtypes)} in _SIGS"
+        for p, t in zip(plist, argtypes):
+            if "*" in p or "umv_stream_t" in p:
+                assert t is ctypes.c_void_p or t is ctypes.c_char_p or hasattr(t, "_type_") and not isinstance(t._type_, str), f"{name}: {p} vs {t}"
+            elif re.search(r"\b(int64_t|size_t|uint64_t)\b", p):
+                assert ctypes.sizeof(t) == 8, f"{name}: {p} vs {t}"
+            elif re.search(r"\bfloat\b", p):
+                assert t is ctypes.c_float, f"{name}: {p} vs {t}"
+            else:
+                assert t in (ctypes.c_int, ctypes.c_uint, ctypes.c_bool), f"{name}: {p} vs {t}"
+    assert set(_lib._SIGS) == {n for n, _ in decls}, set(_lib._SIGS) ^ {n for n, _ in decls}
