@@ -194,6 +194,14 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the whole run on e4m3 LLM weights (BASELINE.json configs[4]); the headline value is the bf16 run")
     ap.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weights decode leg of the default run")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs3"],
+                    help="configs1 (headline): batch 8 x (448x448 + 32-token question); configs3: 32 samples per GPU, 128-token "
+                         "prompts, ViT encode + prefill + --steps decode steps (512 in BASELINE.json)")
+    ap.add_argument("--no-report", action="store_true", help="skip the extra configs[3] leg (32 samples/GPU, 512 decode steps) of the default run")
+    ap.add_argument("--report-steps", type=int, default=512)
+    ap.add_argument("--gather", default="ids", choices=["ids", "logits"],
+                    help="C1 (SURVEY.md 8e): what the ranks all-gather inside the timed region - the generated ids once, or the "
+                         "[B, vocab] bf16 logits of every step")
     ap.add_argument("--fp8-act", type=int, default=1, help="fp8 leg: 1 = W8A8 (e4m3 activations on the fp8 MFMA) for prefill / flow "
                     "passes, 0 = bf16 activations on the bf16 image of the dequantised weights")
     args = ap.parse_args()
@@ -201,10 +209,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1);
+        # rank 0's stdout - the one JSON line - is this process's stdout
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        from unimedvl_amd.launch import spawn_ranks
+        raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -232,6 +247,8 @@ def main():
         img_hw, prompt_len = 56, 8
     cfg.llm_weight_dtype = args.weights
     B = args.batch
+    if args.workload == "configs3" and args.config == "full":
+        B, prompt_len = (32 if args.batch == 8 else args.batch), 128
     t_load = time.time()
     want_t2i = not args.no_t2i
     model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=want_t2i, visual_und=True)
@@ -245,13 +262,15 @@ def main():
     prompts = [torch.randint(min(1000, hi // 2), hi, (prompt_len,), generator=g).tolist() for _ in range(B)]
     images = [synth_image(img_hw, img_hw, 1000 * rank + i) for i in range(B)]
 
-    def decode_leg(model):
+    def decode_leg(model, B=B, prompts=prompts, images=images, prompt_len=prompt_len, steps=args.steps, warmup=args.warmup,
+                   gather=args.gather):
         # ---- prefill: ViT encode + LLM prefill of the image span, then the question
         cache = NaiveCache(cfg.layers)
         kvl, rope = [0] * B, [0] * B
+        torch.cuda.synchronize()
         t0 = time.time()
         gi, kvl, rope = model.prepare_vit_images(kvl, rope, images, lambda x: x, new_token_ids)
-        cache.reserve(B, max(kvl) + prompt_len + 2 + args.steps + args.warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
+        cache.reserve(B, max(kvl) + prompt_len + 2 + steps + warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
         cache = model.forward_cache_update_vit(cache, **gi)
         gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), new_token_ids)
         cache = model.forward_cache_update_text(cache, **gi)
@@ -261,10 +280,17 @@ def main():
 
         # ---- decode
         gi = model.prepare_start_tokens(kvl, rope, new_token_ids)
-        total = args.warmup + args.steps
+        total = warmup + steps
         sess = DecodeSession(model.language_model, cache, gi["packed_start_tokens"], gi["packed_query_position_ids"],
                              total + 1, use_graph=not args.no_graph)
-        sess.step(args.warmup)
+        logits_all = None
+        if dist is not None and gather == "logits":
+            logits_all = torch.empty((world * B, cfg.vocab), dtype=torch.bfloat16, device=dev)
+            sess.step(1)
+            dist.all_gather_into_tensor(logits_all, sess.logits)      # warm the communicator outside the timed region
+            sess.step(warmup - 1) if warmup > 1 else None
+        else:
+            sess.step(warmup)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -272,9 +298,15 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
-        sess.step(args.steps)
-        ids_local = sess.pred_ids[args.warmup:args.warmup + args.steps]
-        if dist is not None:   # C1: the only collective - gather every rank's generated ids over xGMI
+        if logits_all is not None:
+            # C1 as the north star words it: every step's [B, vocab] bf16 logits all-gathered over xGMI (scoring / parity use)
+            for _ in range(steps):
+                sess.step(1)
+                dist.all_gather_into_tensor(logits_all, sess.logits)
+        else:
+            sess.step(steps)
+        ids_local = sess.pred_ids[warmup:warmup + steps]
+        if dist is not None:   # C1: gather every rank's generated ids over xGMI
             gathered = [torch.empty_like(ids_local) for _ in range(world)]
             dist.all_gather(gathered, ids_local.contiguous())
         e1.record()
@@ -290,7 +322,10 @@ def main():
         gpu_ms = e0.elapsed_time(e1)
         sess.commit()
         toks = ids_local.cpu()
-        assert toks.shape == (args.steps, B) and int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab
+        assert toks.shape == (steps, B) and int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab
+        if logits_all is not None:      # the gathered logits of the last step reproduce this rank's last argmax
+            mine = logits_all[rank * B:(rank + 1) * B].float().argmax(-1).cpu()
+            assert torch.equal(mine, toks[-1]), "all-gathered logits do not reproduce the generated ids"
 
         return dict(sess=sess, cache=cache, elapsed=elapsed, gpu_ms=gpu_ms, ctx=ctx, t_prefill=t_prefill)
 

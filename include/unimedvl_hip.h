@@ -88,6 +88,10 @@ typedef struct {
     int64_t split_stride;     /* elements between consecutive splits of `out` */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
+/* Host-only query: the tiled-kernel configuration umv_gemm_bf16 picks for an M x N x K problem (0 for M <= 64, the
+ * weight-streaming kernels; 266 = 256x256x32 interleaved, 268 = 256(n)x128(m), 270 = 128x128, 64 = 128(n)x64(m)x64).
+ * Lets the parity tests assert that a shape reaches the kernel variant it is meant to pin. */
+int umv_gemm_tile_config(int M, int N, int K);
 
 /* ------------------------------------------------------------------ fp8 weights (BASELINE.json configs[4]; no
  * reference counterpart: the reference only has bf16 weights, qwen2_navit.py:541-562 / modeling_qwen2.py:229-235)
@@ -246,6 +250,9 @@ typedef struct {
 } umv_attn_args;
 size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit);
 int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);
+/* Host-only query: which kernel an nsplit = 1 call goes to: 0 = per-wave streaming kernel, 1 / 2 = the LDS-shared
+ * prefill kernel with 1 / 2 query tiles per wave (2 needs >= 512 workgroups). */
+int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q);
 
 /* One decode step's attention with umv_qkv_post folded in (one query token per segment, hd = 128, `und` chain): the wave
  * of a (segment, kv head, key split) normalises + rotates its G query heads and the new key straight from the raw fused QKV

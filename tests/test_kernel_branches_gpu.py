@@ -1,0 +1,274 @@
+"""Every dispatch branch of the two MFMA-bound kernel families, at the shapes the headline bench runs, against an fp32
+reference of the same op (VERDICT r01 "missing" #1 / "next" #2).
+
+The tiny-model goldens only reach the 128x64 GEMM tile and the TQ = 1 attention kernels; the variants that carry the
+bench - gemm_tiled_kernel<2,4,8,4,1,4,1> (cfg 266: hand-interleaved 256x256x32), <4,2,...,1> (268), <2,2,...,1> (270) and
+attn_prefill_kernel<128|72, 2> (two q-tiles per wave, hand-placed MFMA wait states) - are pinned here:
+  * the shape -> kernel policy is asserted through the host-only queries umv_gemm_tile_config / umv_attn_prefill_tq,
+    so a policy change cannot silently move these cases onto another kernel;
+  * GEMM reference: torch fp32 matmul on the same device (fp32 accumulate, rounded once to bf16 like the kernel);
+  * attention reference: fp32 scores / softmax, P rounded to bf16 before PV (the flash-attn model the oracle uses,
+    oracle/unimedvl_cpu.py::attention_segment impl="flash"), evaluated in fp32 on the device;
+  * tools/attn_ab.py's sha compare (per-wave kernel == LDS-shared TQ=1 == TQ=2, bit for bit) runs as a test.
+Reference call sites: qwen2_navit.py:605-614, siglip_navit.py:232-241 (attention); every nn.Linear of the LLM / ViT.
+"""
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from unimedvl_amd import ops as o
+    return o
+
+
+def _lib():
+    from unimedvl_amd import _lib
+    return _lib.load()
+
+
+def ulp_diff(a, b):
+    def key(t):
+        i = t.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(i >= 0x8000, 0x8000 - i, i)
+    return (key(a) - key(b)).abs()
+
+
+def check_bf16(got, ref, max_ulp, frac_exact, what, mag=None):
+    """got / ref bf16 on the device: no element further than max_ulp (unless absolutely tiny), >= frac_exact bit-exact.
+    mag (optional, fp32): magnitude of the largest intermediate behind each element (a residual add can cancel: one ulp of
+    the rounded GEMM result is then several ulps of the sum) - the element passes if it is within max_ulp ulps OF mag."""
+    assert got.shape == ref.shape
+    d = ulp_diff(got, ref)
+    absd = (got.float() - ref.float()).abs()
+    scale = ref.float().abs().max().clamp_min(1e-6)
+    bad = (d > max_ulp) & (absd > scale * 2 ** -8)
+    if mag is not None:
+        bad &= absd > max_ulp * 2.0 ** -7 * mag.abs()
+    assert int(bad.sum()) == 0, f"{what}: {int(bad.sum())} elements off by more than {max_ulp} ulp; worst abs {float(absd.max()):.4g}"
+    exact = (d == 0).float().mean().item()
+    assert exact >= frac_exact, f"{what}: only {exact:.4f} bit-exact"
+    return exact
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(BF16)
+
+
+def _mm(x, w):
+    """fp32 reference x @ w^T in row chunks (keeps the fp32 copies small)."""
+    wf = w.float()
+    return torch.cat([x[i:i + 2048].float() @ wf.T for i in range(0, x.shape[0], 2048)], 0)
+
+
+# (M, N, K, epilogue, expected tile config).  266: the bench's prefill shapes (8208 = 8 x 1026 image-span tokens,
+# 8192 = 8 x 1024 ViT patches, 2064 = 8 flow segments of 258); 268 / 270: what short prefills and single images get.
+TILED = [
+    (4096, 4096, 4096, "bias", 266),
+    (8208, 4608, 3584, "bias", 266),          # LLM QKV, 8 image spans
+    (8208, 3584, 3584, "residual", 266),      # o_proj + residual
+    (8208, 3584, 18944, "residual", 266),     # down_proj + residual
+    (8208, 37888, 3584, "swiglu", 266),       # gate/up SwiGLU
+    (8192, 3456, 1152, "bias", 266),          # ViT fused q/k/v
+    (8192, 4304, 1152, "gelu", 266),          # ViT fc1 + GELU-tanh
+    (8192, 1152, 4304, "residual", 266),      # ViT fc2 (+ residual)
+    (2064, 37888, 3584, "swiglu", 266),       # flow pass gate/up
+    (1026, 4608, 3584, "bias", 268),          # single image span QKV
+    (1026, 3584, 3584, "residual", 270),      # single image span o_proj
+    (1026, 3584, 18944, "residual", 270),
+    (272, 4608, 3584, "bias", 64),            # 8 x 34 text tokens
+    (300, 1152, 608, "bias", 64),             # short K (ViT patch embed, 588 padded to 608)
+]
+
+
+@pytest.mark.parametrize("M,N,K,epi,cfg", TILED)
+def test_gemm_tiled_branch(ops, M, N, K, epi, cfg):
+    lib = _lib()
+    n_eff = N
+    assert lib.umv_gemm_tile_config(M, n_eff, K) == cfg, f"policy moved: {M}x{N}x{K} now -> {lib.umv_gemm_tile_config(M, n_eff, K)}"
+    x = rnd((M, K), 1)
+    if epi == "swiglu":
+        I = N // 2
+        wg, wu = rnd((I, K), 2, 1 / math.sqrt(K)), rnd((I, K), 3, 1 / math.sqrt(K))
+        lin = ops.PackedLinear.from_gate_up(wg, wu)
+        out = ops.gemm(x, lin)
+        ref = F.silu(_mm(x, wg).to(BF16)) * _mm(x, wu).to(BF16)     # modeling_qwen2.py:235, bf16 after every op
+        # a 1-ulp flip of gate or up moves the product by one ulp; flips are rare (fp32 accumulation order only)
+        check_bf16(out, ref, 2, 0.97, f"swiglu {M}x{N}x{K}")
+        return
+    w, b = rnd((N, K), 2, 1 / math.sqrt(K)), rnd((N,), 3)
+    base = _mm(x, w)
+    if epi == "bias":
+        out = ops.gemm(x, ops.PackedLinear.from_weight(w, b))
+        ref = (base + b.float()).to(BF16)
+    elif epi == "gelu":
+        out = ops.gemm(x, ops.PackedLinear.from_weight(w, b), act="gelu_tanh")
+        ref = F.gelu((base + b.float()).to(BF16), approximate="tanh")       # siglip_navit.py:256-257
+    else:
+        res = rnd((M, N), 4)
+        out = ops.gemm(x, ops.PackedLinear.from_weight(w), residual=res)
+        ref = res + base.to(BF16)                                           # qwen2_navit.py:883,900
+        return check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}", mag=torch.maximum(base.abs(), res.float().abs()))
+    check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,n_text,N,K,cfg", [(2064, 16, 4608, 3584, 266), (2064, 16, 3584, 18944, 268), (1032, 8, 4608, 3584, 268)])
+def test_gemm_tiled_row_indexed_mot(ops, M, n_text, N, K, cfg):
+    """MoT routing at flow-pass size (qwen2_navit.py:552-562,891-898): the latent rows go through the tiled kernel by a row
+    index list, the marker-token rows through the weight-streaming kernel, into one output buffer."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    perm = torch.randperm(M, generator=g)
+    text_rows, vae_rows = perm[:n_text].sort().values.to(torch.int32).cuda(), perm[n_text:].sort().values.to(torch.int32).cuda()
+    assert lib.umv_gemm_tile_config(M - n_text, N, K) == cfg
+    x = rnd((M, K), 11)
+    wu, wg_, b = rnd((N, K), 12, 1 / math.sqrt(K)), rnd((N, K), 13, 1 / math.sqrt(K)), rnd((N,), 14)
+    res = rnd((M, N), 15)
+    out = res.clone()
+    ops.gemm(x, ops.PackedLinear.from_weight(wu, b), out=out, M=n_text, row_idx=text_rows, residual=out)
+    ops.gemm(x, ops.PackedLinear.from_weight(wg_, b), out=out, M=M - n_text, row_idx=vae_rows, residual=out)
+    tl, vl = text_rows.long(), vae_rows.long()
+    base = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    base[tl] = _mm(x[tl], wu) + b.float()
+    base[vl] = _mm(x[vl], wg_) + b.float()
+    ref = res + base.to(BF16)
+    check_bf16(out, ref, 1, 0.98, f"row-indexed {M}x{N}x{K}", mag=torch.maximum(base.abs(), res.float().abs()))
+
+
+@pytest.mark.parametrize("M,N,K,swiglu", [(8, 37888, 3584, True), (8, 152064, 3584, False), (32, 37888, 3584, True),
+                                          (32, 152064, 3584, False), (64, 37888, 3584, True), (48, 3584, 18944, False)])
+def test_gemm_skinny_headline_shapes(ops, M, N, K, swiglu):
+    """the dominant decode kernels at their real N (gate/up N = 37 888, lm_head N = 152 064) for B = 8 / 32 / 64 rows"""
+    x = rnd((M, K), 21)
+    if swiglu:
+        wg, wu = rnd((N // 2, K), 22, 1 / math.sqrt(K)), rnd((N // 2, K), 23, 1 / math.sqrt(K))
+        out = ops.gemm(x, ops.PackedLinear.from_gate_up(wg, wu))
+        ref = F.silu(_mm(x, wg).to(BF16)) * _mm(x, wu).to(BF16)
+        check_bf16(out, ref, 2, 0.97, f"skinny swiglu {M}x{N}x{K}")
+    else:
+        w = rnd((N, K), 22, 1 / math.sqrt(K))
+        out = ops.gemm(x, ops.PackedLinear.from_weight(w))
+        check_bf16(out, _mm(x, w).to(BF16), 1, 0.98, f"skinny {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,S", [(8, 4608, 3584, 3), (8, 3584, 3584, 4), (8, 3584, 18944, 4), (32, 3584, 18944, 4), (64, 4608, 3584, 3)])
+def test_gemm_splitk_partials_sum_to_fp32_reference(ops, M, N, K, S):
+    """split-K decode mode (decode.py::_step): the fp32 partial sums of the K splits add up to x @ W^T"""
+    x, w = rnd((M, K), 31), rnd((N, K), 32, 1 / math.sqrt(K))
+    part = torch.empty((S, M, N), dtype=torch.float32, device="cuda")
+    ops.gemm_splitk(x, ops.PackedLinear.from_weight(w), part, S)
+    got = part.sum(0)
+    ref = _mm(x, w)
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * math.sqrt(K) * ref.abs().max().item() + 1e-6, f"split-K fp32 sum differs by {err}"
+    check_bf16(got.to(BF16), ref.to(BF16), 1, 0.98, "split-K")
+
+
+# ---------------------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, ks, vs, q_lens, causal):
+    """flash-attn model in fp32 on the device: S = QK^T/sqrt(d) (+ bottom-right causal mask), fp32 softmax, P rounded to
+    bf16 before PV, fp32 accumulate, one division, bf16 out (oracle/unimedvl_cpu.py::attention_segment impl='flash')."""
+    out = torch.empty_like(q)
+    t0 = 0
+    for i, lq in enumerate(q_lens):
+        k, v = ks[i], vs[i]
+        lk = k.shape[0]
+        rep = q.shape[1] // k.shape[1]
+        qf = q[t0:t0 + lq].float().transpose(0, 1)
+        kf = k.float().transpose(0, 1).repeat_interleave(rep, dim=0)
+        vf = v.float().transpose(0, 1).repeat_interleave(rep, dim=0)
+        s = qf @ kf.transpose(1, 2) / math.sqrt(q.shape[-1])
+        if causal:
+            mask = torch.ones(lq, lk, dtype=torch.bool, device=q.device).tril(diagonal=lk - lq)
+            s = s.masked_fill(~mask, float("-inf"))
+        m = s.max(-1, keepdim=True).values
+        p = torch.exp(s - m)
+        l = p.sum(-1, keepdim=True)
+        o = (p.to(BF16).float() @ vf) / l
+        out[t0:t0 + lq] = o.transpose(0, 1).to(BF16)
+        t0 += lq
+    return out
+
+
+def _attn_run(ops, nq, nkv, hd, q_lens, k_lens, causal, seed, want_tq):
+    lib = _lib()
+    nseg = len(q_lens)
+    tq = lib.umv_attn_prefill_tq(nseg, nq, nkv, hd, max(q_lens))
+    assert tq == want_tq, f"policy moved: this case now runs TQ={tq}, the test is meant to pin TQ={want_tq}"
+    cap = (max(k_lens) + 31) // 32 * 32
+    slab = ops.KVSlab(nseg, nkv, cap, hd, "cuda")
+    slab.k.fill_(1e4)          # a key / value beyond kv_len that is not masked (p = 0 exactly) wrecks the output
+    slab.vt.fill_(1e4)
+    T = sum(q_lens)
+    q = rnd((T, nq, hd), seed)
+    ks = [rnd((lk, nkv, hd), seed + 1 + i) for i, lk in enumerate(k_lens)]
+    vs = [rnd((lk, nkv, hd), seed + 100 + i) for i, lk in enumerate(k_lens)]
+    for i, lk in enumerate(k_lens):
+        slab.k[i, :, :lk] = ks[i].transpose(0, 1)
+        slab.vt[i, :, :, :lk] = vs[i].permute(1, 2, 0)
+    cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32).cuda()
+    out = torch.zeros((T, nq, hd), dtype=BF16, device="cuda")
+    ops.attention(q, out, slab, cu, torch.tensor(k_lens, dtype=torch.int32).cuda(), nq, nkv, hd, causal, max(q_lens), max(k_lens))
+    ref = _attn_ref(q, ks, vs, q_lens, causal)
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref.float()).abs().max().item()
+    assert err < 0.03, f"attention max abs err {err}"
+    # online softmax in key blocks vs one global max: P is rounded to bf16 against a different running max, so single
+    # elements move by a few ulp; bound the tail and require the bulk to agree
+    check_bf16(out, ref, 4, 0.5, f"attention hd{hd} TQ{want_tq}")
+    return out
+
+
+def test_attn_prefill_tq2_llm_image_span(ops):
+    """8 x 1026-token image spans, non-causal, GQA 28/4, hd 128 (bagel.py:523-615 -> qwen2_navit.py:605-614): 1824 workgroups"""
+    _attn_run(ops, 28, 4, 128, [1026] * 8, [1026] * 8, False, 50, want_tq=2)
+
+
+def test_attn_prefill_tq2_causal_with_context(ops):
+    """ragged causal prefill on top of cached context (text after an image): bottom-right aligned mask, 32-key stages"""
+    _attn_run(ops, 28, 4, 128, [700, 513, 640, 1000], [700 + 1026, 513 + 40, 640, 1000 + 7], True, 60, want_tq=2)
+
+
+def test_attn_prefill_tq2_flow_pass(ops):
+    """12 segments of 258 query tokens over prompt + own tokens (a guided flow step of 4 images x 3 contexts, bagel.py:1120-1171)"""
+    _attn_run(ops, 28, 4, 128, [258] * 12, [130 + 258] * 4 + [258] * 4 + [130 + 258] * 4, False, 70, want_tq=2)
+
+
+def test_attn_prefill_tq2_vit_hd72(ops):
+    """8 x 1024 patches, 16 heads of 72 (siglip_navit.py:232-241), and the ragged NaViT form"""
+    _attn_run(ops, 16, 16, 72, [1024] * 8, [1024] * 8, False, 80, want_tq=2)
+    _attn_run(ops, 16, 16, 72, [1024, 512, 768, 1024, 256, 1000], [1024, 512, 768, 1024, 256, 1000], False, 81, want_tq=2)
+
+
+def test_attn_prefill_tq1_still_covered(ops):
+    _attn_run(ops, 28, 4, 128, [1026], [1026], False, 90, want_tq=1)
+    _attn_run(ops, 16, 16, 72, [1024], [1024], False, 91, want_tq=1)
+
+
+def test_attn_kernel_variants_bit_identical():
+    """tools/attn_ab.py as a test: the per-wave streaming kernel (UMV_ATTN_SHARED=0), the LDS-shared kernel with one
+    q-tile per wave (UMV_ATTN_TQ=1) and with two (UMV_ATTN_TQ=2) produce the same bits on every shape of the script."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    shas = {}
+    for name, env in (("wave", {"UMV_ATTN_SHARED": "0"}), ("tq1", {"UMV_ATTN_TQ": "1"}), ("tq2", {"UMV_ATTN_TQ": "2"})):
+        e = dict(os.environ, **env)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "attn_ab.py")], env=e, capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        shas[name] = [ln.split("sha")[-1].strip() for ln in out.stdout.splitlines() if "sha" in ln]
+        assert len(shas[name]) >= 7, out.stdout
+    assert shas["wave"] == shas["tq1"] == shas["tq2"], shas

@@ -39,9 +39,10 @@ class Bagel(BagelPrep):
             raise RuntimeError("unimedvl_amd needs an MI355X (ROCm) device; there is no CPU fallback")
         BagelPrep.__init__(self, cfg, interpolate_pos)
         self.device = torch.device(device)
-        self.language_model = Qwen2MoT(cfg, LLMWeights(cfg, get, self.device, load_gen=visual_gen), self.device)
-        self.glue = GlueWeights(cfg, get, self.device, visual_gen, visual_und)
-        self.vit_model = SiglipVisionModel(cfg, ViTWeights(cfg, get, self.device), self.device) if visual_und else None
+        with ops.device_scope(self.device):     # weight packing kernels launch on the current device
+            self.language_model = Qwen2MoT(cfg, LLMWeights(cfg, get, self.device, load_gen=visual_gen), self.device)
+            self.glue = GlueWeights(cfg, get, self.device, visual_gen, visual_und)
+            self.vit_model = SiglipVisionModel(cfg, ViTWeights(cfg, get, self.device), self.device) if visual_und else None
         self.vae_model = None
         self.hidden_size = cfg.hidden
         self.use_moe = True
@@ -69,6 +70,7 @@ class Bagel(BagelPrep):
 
     # ------------------------------------------------------------------ text
     @torch.no_grad()
+    @ops.on_device
     def forward_cache_update_text(self, past_key_values: NaiveCache, packed_text_ids, packed_text_position_ids,
                                   text_token_lens, packed_text_indexes=None, packed_key_value_indexes=None,
                                   key_values_lens=None):
@@ -81,6 +83,7 @@ class Bagel(BagelPrep):
         return out.past_key_values
 
     # ------------------------------------------------------------------ ViT images
+    @ops.on_device
     def encode_vit(self, packed_vit_tokens, packed_vit_position_ids, vit_token_seqlens):
         """ViT tower + connector + vit_pos_embed (bagel.py:581-592); returns [N, hidden] bf16 (pre-scatter)."""
         lens = vit_token_seqlens.to("cpu")
@@ -91,6 +94,7 @@ class Bagel(BagelPrep):
         return ops.gemm(h, self.glue.conn2)
 
     @torch.no_grad()
+    @ops.on_device
     def forward_cache_update_vit(self, past_key_values: NaiveCache, packed_text_ids, packed_text_indexes,
                                  packed_vit_tokens, packed_vit_token_indexes, packed_vit_position_ids, vit_token_seqlens,
                                  packed_position_ids, packed_seqlens, packed_indexes=None, packed_key_value_indexes=None,
@@ -111,6 +115,7 @@ class Bagel(BagelPrep):
         return out.past_key_values
 
     # ------------------------------------------------------------------ VAE-encoded images (edit / reconstruction)
+    @ops.on_device
     def time_embed(self, t_values):
         """TimestepEmbedder (modeling_utils.py:87-109) for a vector of timesteps -> [n, hidden] bf16.
         The 256-wide sinusoid is built on the host in fp32 with torch (same bits as the
@@ -125,6 +130,7 @@ class Bagel(BagelPrep):
         return ops.gemm(h, self.glue.time2)
 
     @torch.no_grad()
+    @ops.on_device
     def forward_cache_update_vae(self, vae_model, past_key_values: NaiveCache, padded_images, patchified_vae_latent_shapes,
                                  packed_vae_position_ids, packed_timesteps, packed_vae_token_indexes, packed_text_ids,
                                  packed_text_indexes, packed_position_ids, packed_seqlens, packed_indexes=None,
@@ -150,6 +156,7 @@ class Bagel(BagelPrep):
 
     # ------------------------------------------------------------------ image generation
     @torch.no_grad()
+    @ops.on_device
     def generate_image(self, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
                        packed_vae_token_indexes, packed_seqlens, packed_position_ids, packed_indexes=None,
                        past_key_values: NaiveCache = None, key_values_lens=None, packed_key_value_indexes=None,
@@ -273,7 +280,18 @@ class Bagel(BagelPrep):
         return int(diff.item()) == 0
 
     # ------------------------------------------------------------------ text generation
+    def _sampling_seed(self):
+        """Next 62-bit key for the device-side sampler from a DEDICATED generator seeded with torch.initial_seed(): like the
+        reference's CUDA multinomial (bagel.py:1297-1299) a sampled decode leaves torch's CPU RNG state untouched, so the
+        init noise prepare_vae_latent draws afterwards is what it would have been; torch.manual_seed(s) restarts the stream."""
+        base = torch.initial_seed()
+        if getattr(self, "_sample_gen_base", None) != base:
+            self._sample_gen_base = base
+            self._sample_gen = torch.Generator().manual_seed(base)
+        return int(torch.randint(0, 2 ** 62, (1,), generator=self._sample_gen).item())
+
     @torch.no_grad()
+    @ops.on_device
     def generate_text(self, past_key_values: NaiveCache, packed_key_value_indexes=None, key_values_lens=None,
                       packed_start_tokens=None, packed_query_position_ids=None, max_length: int = 0,
                       do_sample: bool = False, temperature: float = 1.0, end_token_id: int = None,
@@ -283,9 +301,9 @@ class Bagel(BagelPrep):
         (bagel.py:1313); per_sample_eos=True is the batched extension (stops when every sample
         has emitted it; rows after a sample's EOS keep decoding and should be ignored)."""
         # do_sample: softmax(logits / temperature) + multinomial on the device (bagel.py:1297-1299).  The
-        # draw is keyed by a seed taken from torch's CPU generator, so torch.manual_seed(s) makes runs
+        # draw is keyed by a seed derived from torch.initial_seed(), so torch.manual_seed(s) makes runs
         # reproducible; the stream itself is not torch's (no device can reproduce another's RNG).
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0
+        seed = self._sampling_seed() if do_sample else 0
         if key_values_lens is not None and [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
             raise ValueError("key_values_lens disagree with the cache")
         if max_length <= 0:   # nothing to decode (the reference would fail on torch.stack([]) here, bagel.py:1316)
@@ -322,6 +340,7 @@ class Bagel(BagelPrep):
 
     # ------------------------------------------------------------------ convenience (evaluation path)
     @torch.no_grad()
+    @ops.on_device
     def chat(self, tokenizer, new_token_ids, image_transform, images, prompt, max_length: int,
              do_sample: bool = False, temperature: float = 1.0):
         """ViT-only VQA convenience path (bagel.py:1321-1392)."""

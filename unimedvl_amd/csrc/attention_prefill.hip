@@ -265,12 +265,27 @@ static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e,
     return UMV_OK;
 }
 
-int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
+// two q-tiles per wave only when that still leaves >= 2 workgroups per CU (measured: LLM prefill 496 -> 413 us, flow pass
+// 96 -> 83, ViT 152 -> 144; but 34-token text prefill 52 -> 73 us with only 96 workgroups)
+static bool prefill_two_qtiles(int qtiles, int nkv, int nseg) {
     static int tq = -1;
     if (tq < 0) { const char* e = getenv("UMV_ATTN_TQ"); tq = e ? atoi(e) : 0; }
-    // two q-tiles per wave only when that still leaves >= 2 workgroups per CU (measured: LLM prefill 496 -> 413 us, flow pass
-    // 96 -> 83, ViT 152 -> 144; but 34-token text prefill 52 -> 73 us with only 96 workgroups)
-    const bool two = tq == 2 || (tq != 1 && (long)((qtiles + 7) / 8) * a.nkv * a.nseg >= 512);
+    return tq == 2 || (tq != 1 && (long)((qtiles + 7) / 8) * nkv * nseg >= 512);
+}
+
+// Which prefill-attention kernel umv_attn_varlen sends a (nsplit = 1) call to: 0 = the per-wave streaming attn_kernel,
+// 1 / 2 = attn_prefill_kernel<hd, TQ>.  Exported so that tests can assert that a case reaches the TQ = 2 kernels.
+extern "C" int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q) {
+    if (nkv <= 0 || nq % nkv || nseg <= 0 || max_q <= 0) return 0;
+    const int G = nq / nkv;
+    const int QPT = 16 / G > 0 ? 16 / G : 1;
+    const int qtiles = (max_q + QPT - 1) / QPT;
+    if (!(qtiles >= 4 && (hd == 128 || hd == 72) && umv_attn_prefill_enabled())) return 0;
+    return prefill_two_qtiles(qtiles, nkv, nseg) ? 2 : 1;
+}
+
+int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
+    const bool two = prefill_two_qtiles(qtiles, a.nkv, a.nseg);
     if (a.hd == 128) return two ? launch_prefill<128, 2>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1>(a, qtiles, scale_log2e, s);
     return two ? launch_prefill<72, 2>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1>(a, qtiles, scale_log2e, s);
 }

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(const bf16_t* __restrict__
     float best = -1.f;
     int bidx = 0x7fffffff;
     for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float p = rbf(expf(rbf(bf2f(row[i]) / temp) - mx) / sum);
+        const float p = expf(rbf(bf2f(row[i]) / temp) - mx) / sum;   // fp32 probabilities, as autocast's softmax returns them
         const uint64_t h = splitmix64(key + (uint64_t)i);
         const float u = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
         const float q = -logf(u);                                           // Exp(1); q > 0 except u == 1

@@ -954,6 +954,27 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
     return UMV_OK;
 }
 
+// Tile choice from measurements on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles_auto.txt).  The 256x256x32
+// 4-buffer tile with the interleaved schedule wins whenever it yields >= ~144 workgroups (885-1120 TF/s on the
+// prefill / flow / ViT shapes); below that the 256(n) x 128(m) interleaved tile (M ~ 2048: 920-1020 TF/s), then
+// 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
+// UMV_GEMM_TILE=<256|266|258|268|129|130|270|64> overrides (tuning only).
+// Exported so that tests can assert which kernel a shape is sent to (returns 0 for M <= 64: weight-streaming kernels).
+extern "C" int umv_gemm_tile_config(int M, int N, int K) {
+    if (M <= 64) return 0;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("UMV_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    if (force) return force;
+    const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long wg258 = (long)((M + 127) / 128) * ((N + 255) / 256);
+    if (K < 1024) return 64;              // short K: the 4-buffer prologue does not amortise
+    if (wg256 >= 144) return 266;
+    if (wg258 >= 140) return 268;
+    if (wg128 >= 128) return 270;
+    return 64;
+}
+
 extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap != nullptr, UMV_ERR_ARG, "gemm: null args");
     umv_gemm_args a = *ap;
@@ -1005,23 +1026,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
-    // Tile choice from measurements on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tiles_auto.txt).  The 256x256x32
-    // 4-buffer tile with the interleaved schedule wins whenever it yields >= ~144 workgroups (885-1120 TF/s on the
-    // prefill / flow / ViT shapes); below that the 256(n) x 128(m) interleaved tile (M ~ 2048: 920-1020 TF/s), then
-    // 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
-    // UMV_GEMM_TILE=<256|266|258|268|129|130|270|64> overrides (tuning only).
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("UMV_GEMM_TILE"); force = e ? atoi(e) : 0; }
-    const long wg256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const long wg258 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
-    int cfg;
-    if (a.K < 1024) cfg = 64;              // short K: the 4-buffer prologue does not amortise
-    else if (wg256 >= 144) cfg = 266;
-    else if (wg258 >= 140) cfg = 268;
-    else if (wg128 >= 128) cfg = 270;
-    else cfg = 64;
-    if (force) cfg = force;
+    const int cfg = umv_gemm_tile_config(a.M, a.N, a.K);
     if (cfg == 256) return launch_tiled<2, 4, 8, 4, 1, 4>(a, KT, NTT, s);      // 256x256x32, 4 buffers (128 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)

@@ -32,6 +32,14 @@ BF16 = torch.bfloat16
 class DecodeSession:
     def __init__(self, llm, cache: NaiveCache, start_tokens, positions, max_length, use_graph=True, nsplit=None,
                  do_sample=False, temperature=1.0, seed=0):
+        with ops.device_scope(llm.device):
+            self._init(llm, cache, start_tokens, positions, max_length, use_graph, nsplit, do_sample, temperature, seed)
+
+    @property
+    def device(self):
+        return self.dev
+
+    def _init(self, llm, cache, start_tokens, positions, max_length, use_graph, nsplit, do_sample, temperature, seed):
         cfg, dev = llm.cfg, llm.device
         self.llm, self.cache, self.cfg, self.dev = llm, cache, cfg, dev
         B = len(cache.lens)
@@ -44,6 +52,9 @@ class DecodeSession:
         self.ids = start_tokens.to(device=dev, dtype=torch.int64).clone()
         self.tok_seg = torch.arange(B, **i32)
         self.tok_slot = torch.tensor(cache.lens, dtype=torch.int32).to(dev)
+        pmax = int(positions.max()) if positions.numel() else 0
+        if (int(positions.min()) if positions.numel() else 0) < 0 or pmax + max_length >= cfg.max_position:
+            raise ValueError(f"decode would reach rope position {pmax + max_length} >= max_position_embeddings {cfg.max_position}")
         self.tok_pos = positions.to(device=dev, dtype=torch.int32).clone()
         self.kv_len = self.tok_slot + 1
         self.cu_q = torch.arange(B + 1, **i32)
@@ -169,7 +180,7 @@ class DecodeSession:
         # the captured step appends at slot = lens0 and bumps the counters; warm up on a side
         # stream first (lazy module loading), then restore the counters so capture sees a clean state
         saved = [t.clone() for t in (self.ids, self.tok_slot, self.tok_pos, self.kv_len, self.step_idx)]
-        s = torch.cuda.Stream()
+        s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._step()
@@ -183,6 +194,7 @@ class DecodeSession:
         # capture does not execute; counters are still at their initial values
         self.graph = g
 
+    @ops.on_device
     def step(self, n=1):
         for _ in range(n):
             if self.steps_done >= self.max_length:
@@ -195,6 +207,7 @@ class DecodeSession:
 
     # ---- continuous batching support (serving.py): the captured step reads these from device memory, so a slot can be
     # re-pointed at a new request between replays without re-capturing
+    @ops.on_device
     def set_slot(self, b, token, kv_len, pos):
         """Sample b continues from `token` with `kv_len` tokens already in its cache segment and rope position `pos`."""
         self.ids[b:b + 1].fill_(int(token))
@@ -202,6 +215,7 @@ class DecodeSession:
         self.kv_len[b:b + 1].fill_(int(kv_len) + 1)
         self.tok_pos[b:b + 1].fill_(int(pos))
 
+    @ops.on_device
     def rewind_outputs(self):
         """Start writing in_ids / pred_ids at row 0 again (the caller has harvested the previous rows)."""
         self.step_idx.zero_()

@@ -55,14 +55,17 @@ class Qwen2MoT:
         return self._side
 
     # ------------------------------------------------------------------ embeddings / head
+    @ops.on_device
     def embed_tokens(self, ids, out=None, out_rows=None):
         ids = ids.to(device=self.device, dtype=torch.int64)
         return ops.embed_gather(self.w.embed, ids, out=out, out_rows=out_rows)
 
+    @ops.on_device
     def lm_head(self, h):
         return ops.gemm(h, self.w.lm_head)
 
     # ------------------------------------------------------------------ forward
+    @ops.on_device
     def forward_inference(self, packed_query_sequence, query_lens, packed_query_position_ids,
                           packed_query_indexes=None, past_key_values: NaiveCache = None, key_values_lens=None,
                           packed_key_value_indexes=None, update_past_key_values=True, is_causal=True, mode="und",
@@ -93,6 +96,11 @@ class Qwen2MoT:
             slot += list(range(c, c + q))
         meta = torch.tensor([seg, slot], dtype=torch.int32).to(dev, non_blocking=True)
         tok_seg, tok_slot = meta[0], meta[1]
+        # the rotary tables hold cfg.max_position rows and the kernels index them unchecked
+        pmax = int(packed_query_position_ids.max()) if packed_query_position_ids.numel() else 0
+        pmin = int(packed_query_position_ids.min()) if packed_query_position_ids.numel() else 0
+        if pmin < 0 or pmax >= cfg.max_position:
+            raise ValueError(f"position ids must lie in [0, {cfg.max_position}) (max_position_embeddings); got [{pmin}, {pmax}]")
         tok_pos = packed_query_position_ids.to(device=dev, dtype=torch.int32)
         cu = [0]
         for q in qlens:

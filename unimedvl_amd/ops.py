@@ -2,6 +2,7 @@
 streams only).  Every function launches a hand-written gfx950 kernel from
 libunimedvl_hip.so on torch's current stream; there is no fallback path."""
 import ctypes as C
+import functools
 
 import torch
 
@@ -20,6 +21,29 @@ def _stream():
     if _raw_stream is not None:       # ~0.3 us instead of ~3 us for building a torch.cuda.Stream object per launch
         return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(fn):
+    """Method decorator: run with `self.device` as torch's current device.  Every kernel launches on the CURRENT device's
+    current stream (_stream), so an engine built on cuda:N (the scripts' target_gpu_device, interactive_vqa_inferencer.py:60)
+    must make N current around its public entry points; a no-op when it already is."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = torch.device(self.device)
+        if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
+def device_scope(device):
+    """Context manager form of on_device (constructors, where self.device does not exist yet)."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or dev.index is None:
+        import contextlib
+        return contextlib.nullcontext()
+    return torch.cuda.device(dev)
 
 
 def _p(t):
@@ -227,9 +251,14 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         raise _lib.UmvError("act8 needs a linear with the fp8-MFMA image (enable_fp8_mfma)")
     if act8 and M <= 64:
         x = fake_quantize_act(x, M, row_idx)
-    if lin.wp is None and not (act8 and M > 64) and not (lin.w8 is not None and M <= 64 and norm_w is None):
-        raise _lib.UmvError(f"this linear only has fp8 images: M={M} rows need act8=True (W8A8) - the bf16 image was dropped")
-    if act8 and M > 64 and norm_w is None and not out_f32:
+    # which kernel family takes the call (mirrors the branches below exactly, so a dropped image raises instead of crashing)
+    use_a8 = act8 and M > 64 and norm_w is None and not out_f32       # fp8 matrix instruction, e4m3 activations
+    use_w8 = lin.w8 is not None and M <= 64 and norm_w is None        # weight-streaming kernel on the e4m3 image
+    if lin.wp is None and not use_a8 and not use_w8:
+        raise _lib.UmvError(f"this linear only has fp8 images (the bf16 image was dropped by enable_fp8_mfma): M={M} rows with "
+                            f"act8={act8}, out_f32={out_f32}, norm_w={'set' if norm_w is not None else 'None'} need the bf16 kernel - "
+                            "build the weights with enable_fp8_mfma(keep_bf16=True)")
+    if use_a8:
         # W8A8: per-row e4m3 activations (rows gathered through row_idx), fp8 matrix instruction, exact pow2 scales
         ldq = (lin.K + 127) // 128 * 128
         xq = torch.empty((M, ldq), dtype=torch.uint8, device=x.device)
@@ -244,7 +273,7 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
             row_idx=row_idx.data_ptr() if row_idx is not None else None, M=M, N=lin.N, K=lin.K, epilogue=flags)
         check(lib.umv_gemm_fp8a8w(C.byref(a8), _stream()), "umv_gemm_fp8a8w")
         return out
-    if lin.w8 is not None and M <= 64 and norm_w is None:
+    if use_w8:
         a = GemmArgs(
             x=x.data_ptr(), ldx=x.stride(0), wp=lin.w8.data_ptr(),
             bias=lin.bias.data_ptr() if (flags & EPI_BIAS) else None,

@@ -19,6 +19,8 @@ from typing import Any, Deque, Dict, List, Optional
 
 import torch
 
+from . import ops
+
 from .decode import DecodeSession
 from .kvcache import NaiveCache
 
@@ -37,6 +39,7 @@ class ContinuousBatcher:
                  max_new_tokens: int = 256, check_every: int = 16, do_sample: bool = False, temperature: float = 1.0,
                  use_graph: bool = True):
         self.model, self.tokenizer, self.new_token_ids, self.image_transform = model, tokenizer, new_token_ids, image_transform
+        self.device = model.device
         self.slots, self.check_every = int(slots), int(check_every)
         self.max_context, self.default_new = int(max_context), int(max_new_tokens)
         self.do_sample, self.temperature, self.use_graph = do_sample, temperature, use_graph
@@ -62,6 +65,7 @@ class ContinuousBatcher:
         return rid
 
     @torch.no_grad()
+    @ops.on_device
     def run(self) -> Dict[int, str]:
         """Serve everything that has been submitted; returns {request id: answer}."""
         m, cache, B = self.model, self.cache, self.slots
@@ -75,7 +79,7 @@ class ContinuousBatcher:
                 state[b] = self._prefill(b, active[b])
         start = torch.tensor([s[0] for s in state], dtype=torch.int64)
         pos = torch.tensor([s[2] for s in state], dtype=torch.int64)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.do_sample else 0
+        seed = m._sampling_seed() if self.do_sample else 0
         lens_now = list(cache.lens)
         sess = DecodeSession(m.language_model, cache, start, pos, self.check_every, use_graph=self.use_graph,
                              do_sample=self.do_sample, temperature=self.temperature, seed=seed)

@@ -138,6 +138,7 @@ class AutoEncoder:
         return self.conv(o.view(B, H, W, Cc), p + "proj_out", residual=x)
 
     # ------------------------------------------------------------------ encoder / decoder
+    @ops.on_device
     def encoder(self, x_nhwc):
         """Encoder.forward (autoencoder.py:169-187) -> moments NHWC [B,H/8,W/8,2z]."""
         h = self.conv(x_nhwc, "encoder.conv_in")
@@ -152,6 +153,7 @@ class AutoEncoder:
         h = self.groupnorm(h, "encoder.norm_out", True)
         return self.conv(h, "encoder.conv_out")
 
+    @ops.on_device
     def decoder(self, z_nhwc):
         """Decoder.forward (autoencoder.py:240-257) -> NHWC [B,H,W,3]."""
         h = self.conv(z_nhwc, "decoder.conv_in")
@@ -175,6 +177,7 @@ class AutoEncoder:
                    "umv_nchw_f32_to_nhwc_bf16")
         return out
 
+    @ops.on_device
     def encode_moments(self, images):
         return self.encoder(self._to_nhwc(images))
 
@@ -183,6 +186,7 @@ class AutoEncoder:
             noise = torch.randn_like(torch.empty((B, self.z, Hm, Wm), dtype=BF16))
         return noise.to(device=self.device, dtype=BF16).contiguous()
 
+    @ops.on_device
     def encode_packed(self, padded_images, latent_shapes, patch, noise=None):
         """vae.encode + the per-image crop / 2x2 patchify of bagel.py:757-776 -> [sum h*w, p*p*z] bf16."""
         mom = self.encode_moments(padded_images)
@@ -199,6 +203,7 @@ class AutoEncoder:
             off += h * w
         return out
 
+    @ops.on_device
     def encode(self, x, noise=None):
         """AutoEncoder.encode (autoencoder.py:300-303) -> [B,z,H/8,W/8] bf16 (NCHW, like the reference)."""
         mom = self.encode_moments(x)
@@ -206,6 +211,7 @@ class AutoEncoder:
         tok = self.encode_packed_from_moments(mom, noise)
         return tok
 
+    @ops.on_device
     def encode_packed_from_moments(self, mom, noise):
         B, Hm, Wm, _ = mom.shape
         nz = self._noise(B, Hm, Wm, noise)
@@ -218,6 +224,7 @@ class AutoEncoder:
             outs.append(t.view(Hm, Wm, self.z).permute(2, 0, 1))
         return torch.stack(outs, 0)
 
+    @ops.on_device
     def decode_tokens(self, latent_tokens, image_shape, latent_downsample, patch):
         """latent tokens [h*w, p*p*z] -> decoder output NHWC bf16 [1,H,W,3]."""
         H, W = image_shape
@@ -228,6 +235,7 @@ class AutoEncoder:
                                                    self.shift_factor, _stream()), "umv_unpatchify_latent")
         return self.decoder(z)
 
+    @ops.on_device
     def decode_tokens_to_uint8(self, latent_tokens, image_shape, latent_downsample, patch):
         img = self.decode_tokens(latent_tokens, image_shape, latent_downsample, patch)
         _, H, W, Cs = img.shape
@@ -235,6 +243,7 @@ class AutoEncoder:
         _lib.check(self._lib.umv_pixels_to_u8(img.data_ptr(), out.data_ptr(), H * W, Cs, _stream()), "umv_pixels_to_u8")
         return out
 
+    @ops.on_device
     def decode(self, z):
         """AutoEncoder.decode (autoencoder.py:305-307): z [B,z,h,w] -> [B,3,H,W] bf16 (NCHW view)."""
         outs = []

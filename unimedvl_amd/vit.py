@@ -22,6 +22,7 @@ class SiglipVisionModel:
     def __call__(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
         return self.forward(packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen)
 
+    @ops.on_device
     def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
         cfg, w, dev = self.cfg, self.w, self.device
         nh, hd, h_dim = cfg.vit_heads, cfg.vit_head_dim, cfg.vit_hidden
