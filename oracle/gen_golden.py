@@ -272,9 +272,10 @@ def main():
     from PIL import Image
     import inferencer as ref_inferencer
     from oracle.toy_tokenizer import ToyTokenizer
-    from unimedvl_amd.transforms import ImageTransform   # the reference's transform needs torchvision + cv2 (absent)
+    from oracle.ref_import import import_reference_transforms
+    ref_tf = import_reference_transforms()               # the REFERENCE's data/transforms.py over torchvision / cv2 stand-ins
     ttok = ToyTokenizer(NEW_TOKEN_IDS)
-    vae_tf, vit_tf = ImageTransform(64, 32, 16), ImageTransform(56, 28, 14)
+    vae_tf, vit_tf = ref_tf.ImageTransform(64, 32, 16), ref_tf.ImageTransform(56, 28, 14)
     inf = ref_inferencer.InterleaveInferencer(model, vae, ttok, vae_tf, vit_tf, NEW_TOKEN_IDS)
     arr = ((synth_image(50, 40, 61)[0] * 0.5 + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy()
     pil = Image.fromarray(np.stack([arr, arr, arr], -1))
@@ -294,12 +295,58 @@ def main():
         ver1 = inf(image=pil, text="5 6 7 8", inference_ver=1, **rec)
         torch.manual_seed(14)
         ver01 = inf.interleave_inference_for_vqa_reconstruction_ver0_1([pil, "5 6 7 8"], **rec)
+        # think=True (inferencer.py:23-28,590-596,617-620): the English system prompts go through the tokenizer
+        think_und = inf(image=pil, text="5 6 7 8", think=True, understanding_output=True, max_think_token_n=6)
+        torch.manual_seed(15)
+        think_gen = inf(text="40 41 42", think=True, max_think_token_n=5, image_shapes=(64, 64), num_timesteps=3,
+                        cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), timestep_shift=3.0, cfg_renorm_type="global")
+        # Bagel.chat (bagel.py:1321-1392): two images then the prompt, ViT-only context, greedy, stops at eos of sample 0
+        from data.data_utils import pil_img2rgb as ref_pil_img2rgb
+        arr2 = ((synth_image(30, 64, 62)[0] * 0.5 + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy()
+        pil2 = Image.fromarray(arr2)                     # mode "L": pil_img2rgb converts
+        chat_text = model.chat(ttok, dict(NEW_TOKEN_IDS), vit_tf, [ref_pil_img2rgb(pil), ref_pil_img2rgb(pil2)], "5 6 7 8", max_length=8)
     np.savez(os.path.join(OUT, "inferencer.npz"), **pack(dict(
         weights_sha=wdig, pil_image=torch.from_numpy(np.asarray(pil).copy()), und_text=und["text"],
         t2i_image=torch.from_numpy(np.asarray(t2i["image"]).copy()),
         edit_image=torch.from_numpy(np.asarray(edit["image"]).copy()),
         ver1_text=ver1["text"], ver1_image=torch.from_numpy(np.asarray(ver1["image"]).copy()),
-        ver01_text=ver01[0], ver01_image=torch.from_numpy(np.asarray(ver01[1]).copy()))))
+        ver01_text=ver01[0], ver01_image=torch.from_numpy(np.asarray(ver01[1]).copy()),
+        think_und_text=think_und["text"], think_gen_text=think_gen["text"],
+        think_gen_image=torch.from_numpy(np.asarray(think_gen["image"]).copy()),
+        pil_image2=torch.from_numpy(arr2.copy()), chat_text=chat_text)))
+
+    # ------------------------------------------------------------------ I: host image transform (data/transforms.py:15-115)
+    import hashlib
+    psets = [(980, 378, 14, 2_007_040), (980, 387, 14, 14 * 14 * 9 * 1024), (1024, 512, 16, 14 * 14 * 9 * 1024),
+             (64, 32, 16, 14 * 14 * 9 * 1024), (56, 28, 14, 14 * 14 * 9 * 1024), (518, 224, 14, 14 * 14 * 400)]
+    dims = [(448, 448), (1024, 1024), (2000, 1500), (1500, 2000), (3000, 200), (200, 3000), (37, 41), (100, 7), (7, 100),
+            (979, 981), (1400, 1433), (512, 384), (640, 480), (4096, 4096), (13, 13), (980, 378), (377, 979)]
+    rows, outs = [], []
+    for pi, (mx, mn, st, mp) in enumerate(psets):
+        rz = ref_tf.MaxLongEdgeMinShortEdgeResize(max_size=mx, min_size=mn, stride=st, max_pixels=mp)
+        for (w, h) in dims:
+            for img_num in (1, 2, 5):
+                o = rz(Image.new("L", (w, h)), img_num=img_num)
+                rows.append([pi, w, h, img_num])
+                outs.append(list(o.size))
+    rng = np.random.default_rng(77)
+    rgb = Image.fromarray(rng.integers(0, 256, (50, 40, 3), dtype=np.uint8))
+    gray = Image.fromarray(rng.integers(0, 256, (33, 71), dtype=np.uint8))
+    rgba = Image.fromarray(rng.integers(0, 256, (45, 45, 4), dtype=np.uint8), mode="RGBA")
+    big = Image.fromarray(np.random.default_rng(78).integers(0, 256, (600, 437, 3), dtype=np.uint8))   # re-made by seed in the test
+    t_small, t_vae = ref_tf.ImageTransform(56, 28, 14), ref_tf.ImageTransform(64, 32, 16)
+    big_out = ref_tf.ImageTransform(980, 378, 14, max_pixels=2_007_040)(big)
+    u8 = torch.from_numpy(rng.integers(0, 256, (3, 50, 40), dtype=np.uint8))
+    f32 = torch.from_numpy(rng.random((3, 21, 90), dtype=np.float32))
+    np.savez(os.path.join(OUT, "transforms.npz"), **pack(dict(
+        psets=torch.tensor(psets), size_in=torch.tensor(rows), size_out=torch.tensor(outs),
+        rgb=torch.from_numpy(np.asarray(rgb).copy()), gray=torch.from_numpy(np.asarray(gray).copy()),
+        rgba=torch.from_numpy(np.asarray(rgba).copy()),
+        rgb_vit=t_small(ref_pil_img2rgb(rgb)), gray_vit=t_small(ref_pil_img2rgb(gray)), rgba_vae=t_vae(ref_pil_img2rgb(rgba)),
+        rgb_vit_num3=t_small(ref_pil_img2rgb(rgb), img_num=3),
+        big_shape=torch.tensor(list(big_out.shape)),
+        big_sha256=hashlib.sha256(big_out.contiguous().numpy().tobytes()).hexdigest(),
+        u8_in=u8, u8_resized=t_small.resize_transform(u8), f32_in=f32, f32_resized=t_vae.resize_transform(f32))))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(" ", f, os.path.getsize(os.path.join(OUT, f)))

@@ -14,8 +14,11 @@ Shims:
      relies on, modeling_qwen2.py:369-372).
   2. transformers-5 drift: ``ROPE_INIT_FUNCTIONS['default']`` was removed; we
      register the published default rule inv_freq = 1/theta^(arange(0,d,2)/d).
-  3. ``torchvision`` / ``cv2`` are absent; only needed by data.transforms,
-     which we do not import (the oracle passes tensors).
+  3. ``torchvision`` / ``cv2`` are absent; ``install_vision_stubs`` provides the four
+     primitives the reference's data/transforms.py:15-115 calls (F.resize, ToTensor,
+     Normalize, InterpolationMode) so that the reference's OWN size arithmetic
+     (MaxLongEdgeMinShortEdgeResize.forward) and ImageTransform can be imported
+     and run to make fixtures (import_reference_transforms).
 """
 import importlib.machinery
 import os
@@ -69,6 +72,88 @@ def install_shims():
             inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64).float().to(device) / dim))
             return inv, 1.0
         ROPE_INIT_FUNCTIONS["default"] = _default_rope
+
+
+def install_vision_stubs():
+    """cv2 / torchvision stand-ins, just enough for `import data.transforms` (SURVEY.md section 8c shim 3).
+
+    torchvision semantics restated (torchvision 0.20, the version paired with the reference's torch 2.5.1):
+      * F.resize(PIL, (h, w), BICUBIC, antialias) == PIL's Image.resize((w, h), Image.BICUBIC) (F_pil.resize; PIL always
+        antialiases when down-scaling);
+      * F.resize(tensor, (h, w), BICUBIC, antialias=True) == torch interpolate(mode="bicubic", align_corners=False,
+        antialias=True) on a float copy, rounded and clamped back for uint8 inputs (F_t.resize);
+      * ToTensor: HWC uint8 PIL -> CHW float32 / 255;  Normalize(mean, std, inplace=True): (x - mean) / std.
+    """
+    import numpy as np
+    from PIL import Image
+    if "cv2" not in sys.modules:
+        cv2 = types.ModuleType("cv2")
+        cv2.__spec__ = importlib.machinery.ModuleSpec("cv2", None)
+        sys.modules["cv2"] = cv2
+    if "torchvision" in sys.modules:
+        return
+    tv = types.ModuleType("torchvision")
+    tv.__spec__ = importlib.machinery.ModuleSpec("torchvision", None)
+    tr = types.ModuleType("torchvision.transforms")
+    fn = types.ModuleType("torchvision.transforms.functional")
+
+    class InterpolationMode:
+        NEAREST, BILINEAR, BICUBIC = "nearest", "bilinear", "bicubic"
+
+    def resize(img, size, interpolation=InterpolationMode.BILINEAR, max_size=None, antialias=True):
+        h, w = size
+        if isinstance(img, torch.Tensor):
+            if interpolation != InterpolationMode.BICUBIC:
+                raise NotImplementedError(interpolation)
+            x = img if img.dim() == 4 else img.unsqueeze(0)
+            out = F.interpolate(x.to(torch.float32), size=(h, w), mode="bicubic", align_corners=False, antialias=bool(antialias))
+            if img.dtype == torch.uint8:
+                out = out.round().clamp(0, 255).to(torch.uint8)
+            else:
+                out = out.to(img.dtype)
+            return out if img.dim() == 4 else out[0]
+        pil_mode = {InterpolationMode.NEAREST: Image.NEAREST, InterpolationMode.BILINEAR: Image.BILINEAR,
+                    InterpolationMode.BICUBIC: Image.BICUBIC}[interpolation]
+        return img.resize((w, h), pil_mode)
+
+    class ToTensor:
+        def __call__(self, pic):
+            if isinstance(pic, torch.Tensor):
+                raise TypeError("pic should be PIL Image or ndarray")
+            arr = np.asarray(pic)
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            t = torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous()
+            return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
+
+    class Normalize:
+        def __init__(self, mean, std, inplace=False):
+            self.mean, self.std, self.inplace = mean, std, inplace
+
+        def __call__(self, t):
+            if not self.inplace:
+                t = t.clone()
+            mean = torch.as_tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)
+            std = torch.as_tensor(self.std, dtype=t.dtype).view(-1, 1, 1)
+            return t.sub_(mean).div_(std)
+
+    fn.resize = resize
+    fn.InterpolationMode = InterpolationMode
+    tr.functional, tr.InterpolationMode, tr.ToTensor, tr.Normalize = fn, InterpolationMode, ToTensor, Normalize
+    tv.transforms = tr
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.transforms.functional": fn})
+
+
+def import_reference_transforms():
+    """The reference's data/transforms.py (ImageTransform, MaxLongEdgeMinShortEdgeResize) over the stubs above."""
+    if not os.path.isdir(REF_ROOT):
+        raise RuntimeError(f"reference not present at {REF_ROOT}")
+    sys.dont_write_bytecode = True
+    install_vision_stubs()
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    import data.transforms as ref_tf
+    return ref_tf
 
 
 def import_reference():

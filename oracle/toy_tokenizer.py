@@ -1,6 +1,6 @@
 """Toy tokenizer for the parity tests (TEST INFRASTRUCTURE).  The real Qwen2 BPE vocabulary
 ships with the checkpoint, which is not available offline.  Text is a space-separated list
-of integers; special ids render as the markers the reference's post-processing splits on
+of integers (other words hash to ids); special ids render as the markers the reference's post-processing splits on
 (codes/inferencer.py:277-278)."""
 
 
@@ -10,7 +10,10 @@ class ToyTokenizer:
                       new_token_ids["start_of_image"]: "<|vision_start|>", new_token_ids["end_of_image"]: "<|vision_end|>"}
 
     def encode(self, s):
-        return [int(x) for x in s.split()]
+        """integers stand for themselves; any other word (the reference's English think prompts, inferencer.py:23-28)
+        hashes to a stable id in [5, 290)"""
+        import zlib
+        return [int(x) if x.lstrip("-").isdigit() else zlib.crc32(x.encode()) % 285 + 5 for x in s.split()]
 
     def decode(self, ids):
         out = []

@@ -95,6 +95,33 @@ def test_vqa_reconstruction_variants(stack):
     assert inf.interleave_inference_for_vqa_reconstruction_ver0([pil, "5 6 7 8"], max_think_token_n=6) == [g["ver01_text"]]
 
 
+def test_think_mode_and_chat_vs_reference(stack):
+    """think=True (inferencer.py:23-28,590-596,617-620: system prompt prefilled into gen / cfg_img contexts, think text generated
+    and fed back before the image) and Bagel.chat (bagel.py:1321-1392: images then prompt, ViT-only context, stops at sample
+    0's eos) against the REFERENCE's own outputs (tests/golden/inferencer.npz, oracle/gen_golden.py section H)."""
+    from unimedvl_amd.data_utils import pil_img2rgb
+    from unimedvl_amd.inferencer import GEN_THINK_SYSTEM_PROMPT, VLM_THINK_SYSTEM_PROMPT, InterleaveInferencer
+    from unimedvl_amd.transforms import ImageTransform
+    model, vae, tok = stack
+    g = load_golden("inferencer")
+    pil = Image.fromarray(g["pil_image"].numpy())
+    assert len(tok.encode(VLM_THINK_SYSTEM_PROMPT)) > 20 and tok.encode(GEN_THINK_SYSTEM_PROMPT) != tok.encode(VLM_THINK_SYSTEM_PROMPT)
+    vit_tf = ImageTransform(56, 28, 14)
+    inf = InterleaveInferencer(model, vae, tok, ImageTransform(64, 32, 16), vit_tf, NEW_TOKEN_IDS)
+    und = inf(image=pil, text="5 6 7 8", think=True, understanding_output=True, max_think_token_n=6)
+    assert und["image"] is None and und["text"] == g["think_und_text"], (und["text"], g["think_und_text"])
+    assert und["text"] != g["und_text"], "the think system prompt must change the context"
+    torch.manual_seed(15)
+    gen = inf(text="40 41 42", think=True, max_think_token_n=5, image_shapes=(64, 64), num_timesteps=3, cfg_text_scale=4.0,
+              cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), timestep_shift=3.0, cfg_renorm_type="global")
+    assert gen["text"] == g["think_gen_text"], (gen["text"], g["think_gen_text"])
+    pixel_close(gen["image"], g["think_gen_image"], "think + t2i")
+    pil2 = Image.fromarray(g["pil_image2"].numpy())
+    assert pil2.mode == "L"
+    ans = model.chat(tok, dict(NEW_TOKEN_IDS), vit_tf, [pil_img2rgb(pil), pil_img2rgb(pil2)], "5 6 7 8", max_length=8)
+    assert ans == g["chat_text"], (ans, g["chat_text"])
+
+
 def test_batched_call_matches_single_calls(stack):
     """Batch extension: lists in, list of dicts out, per-sample EOS.  Samples are independent
     segments, so a batched greedy VQA run must give each sample the answer its own single-sample call gives

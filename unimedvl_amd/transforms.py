@@ -1,8 +1,10 @@
 """Inference-time image transform with the reference's interface
 (codes/data/transforms.py:15-115): ``ImageTransform(max, min, stride)(pil) -> [3,H,W]`` in
 [-1,1] and ``.resize_transform`` exposing max_size / min_size / stride / max_pixels
-(read by InterleaveInferencer._calculate_target_size_with_aspect_ratio).  PIL-only:
-torchvision's F.resize on a PIL image is PIL's own BICUBIC resize."""
+(read by InterleaveInferencer._calculate_target_size_with_aspect_ratio).  No torchvision:
+its F.resize on a PIL image is PIL's own BICUBIC resize, on a tensor torch's antialiased
+bicubic interpolate.  Pinned to the reference's own module by tests/golden/transforms.npz
+(tests/test_transforms_cpu.py)."""
 import numpy as np
 import torch
 from PIL import Image
@@ -32,7 +34,15 @@ class MaxLongEdgeMinShortEdgeResize:
 
     def __call__(self, img, img_num=1):
         if isinstance(img, torch.Tensor):
-            raise TypeError("resize expects a PIL image")
+            # tensor input [..., H, W] (transforms.py:64-65 -> torchvision's tensor resize): bicubic, align_corners=False,
+            # antialias; uint8 inputs are rounded and clamped back
+            height, width = img.shape[-2:]
+            nw, nh = self.target_size(width, height, img_num=img_num)
+            x = img if img.dim() == 4 else img.unsqueeze(0)
+            out = torch.nn.functional.interpolate(x.to(torch.float32), size=(nh, nw), mode="bicubic", align_corners=False,
+                                                  antialias=bool(self.antialias))
+            out = out.round().clamp(0, 255).to(torch.uint8) if img.dtype == torch.uint8 else out.to(img.dtype)
+            return out if img.dim() == 4 else out[0]
         nw, nh = self.target_size(*img.size, img_num=img_num)
         return img.resize((nw, nh), self.interpolation)
 
