@@ -86,6 +86,11 @@ typedef struct {
                                  (umv_qkv_post partials input, umv_residual_rmsnorm_bf16) adds the splits in order 0..S-1 and
                                  finishes the row with the reference's roundings */
     int64_t split_stride;     /* elements between consecutive splits of `out` */
+    uint64_t* argmax_partial; /* optional [M][ceil(N/16)] (M <= 64, bf16 out, plain 16-row image): greedy argmax as an epilogue of
+                                 the lm_head GEMM (bagel.py:1295-1301).  Every 16-column tile writes one key per row:
+                                 (order-preserving image of the stored bf16 logit) << 32 | (0xFFFFFFFF - column); the maximum
+                                 key over a row is torch.argmax(logits) (lowest index on ties, NaN highest).  Finished by
+                                 umv_decode_step_end_argmax.  The logits are still written to `out`. */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 /* Host-only query: the tiled-kernel configuration umv_gemm_bf16 picks for an M x N x K problem (0 for M <= 64, the
@@ -291,6 +296,13 @@ int umv_decode_advance(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, int
  * in_ids[0] holds the start tokens, bagel.py:1263), counters += 1, step_idx[0] = s + 1.  in_ids / pred_ids are [max_len][B]. */
 int umv_decode_step_end(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const int64_t* ids, int64_t* in_ids,
                         int64_t* pred_ids, int64_t* step_idx, int B, int max_len, umv_stream_t stream);
+/* umv_decode_step_end with the greedy pick folded in: ids[b] = column of the maximum key of argmax_partial[b][0..n_tiles)
+ * (written by umv_gemm_bf16 / umv_gemm_fp8w with argmax_partial set), then the bookkeeping above.  `ids` is an OUTPUT here
+ * (the token the next step embeds).  One workgroup per sample; `ticket` is one zero-initialised int32 owned by the caller
+ * (the last workgroup to arrive advances step_idx and resets it). */
+int umv_decode_step_end_argmax(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const uint64_t* argmax_partial, int n_tiles,
+                               int64_t* ids, int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int32_t* ticket, int B,
+                               int max_len, umv_stream_t stream);
 
 /* Stream `bytes` at `ptr` through the cache hierarchy (no compute) so that they are resident in the
  * 256 MiB Infinity Cache for a later kernel; meant for a parallel stream / graph branch during the

@@ -162,3 +162,26 @@ def test_graph_replay_equals_eager(full):
     for x, y in zip(*runs):
         assert torch.equal(x, y)
     assert torch.equal(runs[0][1][0].cpu(), start) and torch.equal(runs[0][1][1:5], runs[0][0][:4])   # in_ids = start, then the predictions
+
+
+def test_fused_argmax_equals_separate_argmax(full, monkeypatch):
+    """the greedy pick as the lm_head epilogue (default) and as the separate argmax kernel decode the same tokens, logits
+    and counters at full vocabulary width (N = 152 064, 9504 tiles per row)"""
+    from copy import deepcopy
+    from unimedvl_amd.decode import DecodeSession
+    model, cfg, ids = full
+    prompts = _prompts([40, 12, 77, 5, 64, 33, 90, 21], 9)
+    B = len(prompts)
+    cache, kvl, rope = _prefill(model, cfg, prompts, ids)
+    start = torch.full((B,), ids["bos_token_id"], dtype=torch.int64)
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("UMV_DECODE_FUSED_ARGMAX", fused)
+        sess = DecodeSession(model.language_model, deepcopy(cache), start, torch.tensor(rope), 7, use_graph=True)
+        assert sess.fused_argmax == (fused == "1")
+        sess.step(6)
+        runs.append((sess.pred_ids.clone(), sess.in_ids.clone(), sess.logits.clone(), sess.tok_pos.clone(), sess.kv_len.clone(),
+                     sess.step_idx.clone(), sess.ids.clone()))
+    for x, y in zip(*runs):
+        assert torch.equal(x, y)
+    assert int(runs[0][5]) == 6

@@ -46,7 +46,7 @@ def ulp_diff(a, b):
     return (key(a) - key(b)).abs()
 
 
-def check_bf16(got, ref, max_ulp, frac_exact, what, mag=None):
+def check_bf16(got, ref, max_ulp, frac_exact, what, mag=None, two_roundings=False):
     """got / ref bf16 on the device: no element further than max_ulp (unless absolutely tiny), >= frac_exact bit-exact.
     mag (optional, fp32): magnitude of the largest intermediate behind each element (a residual add can cancel: one ulp of
     the rounded GEMM result is then several ulps of the sum; or carry into the next binade) - the element passes if it is
@@ -58,6 +58,13 @@ def check_bf16(got, ref, max_ulp, frac_exact, what, mag=None):
     bad = (d > max_ulp) & (absd > scale * 2 ** -8)
     if mag is not None:
         bad &= absd > max_ulp * 2.0 ** -7 * mag.abs()
+    if two_roundings:
+        # epilogues that round twice (GEMM result -> bf16, then + residual / GELU -> bf16): a one-ulp flip of the first
+        # rounding (fp32 summation order at an exact tie) can land the second on a tie as well and come out 2 ulps apart
+        # (tools/dbg_branch.py prints such elements with their fp64 sums); allow that for at most 1 element in 100 000
+        over = bad & (d <= 2)
+        assert float(over.float().mean()) <= 1e-5, f"{what}: {int(over.sum())} elements 2 ulps off"
+        bad &= d > 2
     assert int(bad.sum()) == 0, f"{what}: {int(bad.sum())} elements off by more than {max_ulp} ulp; worst abs {float(absd.max()):.4g}"
     exact = (d == 0).float().mean().item()
     assert exact >= frac_exact, f"{what}: only {exact:.4f} bit-exact"
@@ -123,9 +130,9 @@ def test_gemm_tiled_branch(ops, M, N, K, epi, cfg):
         out = ops.gemm(x, ops.PackedLinear.from_weight(w), residual=res)
         ref = res + base.to(BF16)                                           # qwen2_navit.py:883,900
         mag = torch.maximum(torch.maximum(base.abs(), res.float().abs()), ref.float().abs())
-        check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}", mag=mag)
+        check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}", mag=mag, two_roundings=True)
         return
-    check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}")
+    check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}", two_roundings=(epi == "gelu"))
 
 
 @pytest.mark.parametrize("M,n_text,N,K,cfg", [(2064, 16, 4608, 3584, 266), (2064, 16, 3584, 18944, 268), (1032, 8, 4608, 3584, 268)])
@@ -149,7 +156,7 @@ def test_gemm_tiled_row_indexed_mot(ops, M, n_text, N, K, cfg):
     base[vl] = _mm(x[vl], wg_) + b.float()
     ref = res + base.to(BF16)
     mag = torch.maximum(torch.maximum(base.abs(), res.float().abs()), ref.float().abs())
-    check_bf16(out, ref, 1, 0.98, f"row-indexed {M}x{N}x{K}", mag=mag)
+    check_bf16(out, ref, 1, 0.98, f"row-indexed {M}x{N}x{K}", mag=mag, two_roundings=True)
 
 
 @pytest.mark.parametrize("M,N,K,swiglu", [(8, 37888, 3584, True), (8, 152064, 3584, False), (32, 37888, 3584, True),

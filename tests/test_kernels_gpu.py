@@ -373,3 +373,42 @@ def test_qkv_post_many_tokens_matches_small_calls(ops, gen):
         assert torch.equal(x, y)
     written = (whole[2] != 3.0).sum().item()      # a few random values may equal the fill by chance
     assert T * nkv * hd - 64 <= written <= T * nkv * hd
+
+
+@pytest.mark.parametrize("M,N,K,fp8", [(8, 152064, 3584, False), (1, 1000, 256, False), (33, 4112, 512, False), (64, 37888, 1152, False),
+                                       (8, 152064, 3584, True), (20, 1000, 256, True)])
+def test_gemm_argmax_epilogue(ops, M, N, K, fp8):
+    """greedy argmax as the lm_head epilogue (bagel.py:1295-1301): the per-tile keys + umv_decode_step_end_argmax pick
+    torch.argmax of the stored bf16 logits, lowest index on ties (two identical weight rows -> identical logits), and do
+    decode_step_end's bookkeeping."""
+    x, w = rnd((M, K), 90), rnd((N, K), 91, 1 / math.sqrt(K))
+    w[N // 3] = w[N - 5]                       # exact ties between two far-apart columns
+    w[7] = w[N - 5]
+    mk = ops.PackedLinear.from_weight_fp8 if fp8 else ops.PackedLinear.from_weight
+    lin = mk(w.cuda())
+    part = torch.zeros((M, (N + 15) // 16), dtype=torch.int64, device="cuda")
+    logits = ops.gemm(x.cuda(), lin, argmax_partial=part)
+    plain = ops.gemm(x.cuda(), lin)
+    assert torch.equal(logits, plain), "the argmax epilogue must not change the logits"
+    B, max_len = M, 5
+    i32 = dict(dtype=torch.int32, device="cuda")
+    slot, pos, kvl = torch.arange(B, **i32), torch.arange(B, **i32) + 100, torch.arange(B, **i32) + 1
+    ids = torch.full((B,), -1, dtype=torch.int64, device="cuda")
+    in_ids = torch.zeros((max_len, B), dtype=torch.int64, device="cuda")
+    pred = torch.zeros((max_len, B), dtype=torch.int64, device="cuda")
+    step = torch.tensor([2], dtype=torch.int64, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.decode_step_end_argmax(slot, pos, kvl, part, ids, in_ids, pred, step, ticket)
+    ref = torch.argmax(logits.float(), -1)
+    assert torch.equal(ids, ref), (ids.tolist()[:8], ref.tolist()[:8])
+    tie_rows = (logits[:, 7] == logits.float().max(-1).values.to(logits.dtype))
+    assert torch.equal(ids[tie_rows], torch.full_like(ids[tie_rows], 7))
+    assert torch.equal(pred[2], ref) and torch.equal(in_ids[3], ref) and int(pred[3].abs().sum()) == 0
+    assert int(step) == 3 and int(ticket) == 0
+    assert torch.equal(slot, torch.arange(B, **i32) + 1) and torch.equal(pos, torch.arange(B, **i32) + 101)
+    # a second step through the same buffers (the ticket was reset)
+    ops.decode_step_end_argmax(slot, pos, kvl, part, ids, in_ids, pred, step, ticket)
+    assert int(step) == 4 and torch.equal(pred[3], ref) and torch.equal(in_ids[4], ref)
+    with pytest.raises(Exception):
+        ops.gemm(rnd((100, K), 92).cuda(), lin if not fp8 else ops.PackedLinear.from_weight(w.cuda()),
+                 argmax_partial=torch.zeros((100, (N + 15) // 16), dtype=torch.int64, device="cuda"))

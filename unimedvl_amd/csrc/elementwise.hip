@@ -343,6 +343,13 @@ extern "C" int umv_add_rows_bf16(const uint16_t* a, const uint16_t* bcast, const
     return UMV_OK;
 }
 
+__device__ __forceinline__ uint64_t shfl_xor_u64_ew(uint64_t v, int mask) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl_xor((int)lo, mask, 64);
+    hi = (uint32_t)__shfl_xor((int)hi, mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ----------------------------------------------------------------------------- argmax (bf16 logits, lowest index wins)
 __global__ __launch_bounds__(1024) void argmax_kernel(const bf16_t* __restrict__ logits, int64_t ld, int64_t* __restrict__ out, int V) {
     __shared__ float smax[16];
@@ -732,6 +739,63 @@ extern "C" int umv_decode_step_end(int32_t* tok_slot, int32_t* tok_pos, int32_t*
     if (B == 0) return UMV_OK;
     hipLaunchKernelGGL(decode_step_end_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tok_slot, tok_pos, kv_len, ids, in_ids, pred_ids,
                        step_idx, B, max_len);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+// Greedy pick + end of step in one launch: one workgroup per sample takes the maximum of the per-tile keys the lm_head GEMM
+// epilogue left (gemm_epilogue.h::argmax_key), then does decode_step_end_kernel's bookkeeping for its sample.  Every
+// workgroup reads s = step_idx[0] BEFORE it takes a ticket and the last ticket holder writes s + 1, so no workgroup can see
+// the new value (relaxed device-scope atomics on one word; the kernel boundary publishes everything else).
+__global__ __launch_bounds__(256) void decode_step_end_argmax_kernel(int32_t* slot, int32_t* pos, int32_t* kv_len,
+                                                                     const uint64_t* __restrict__ part, int n_tiles, int64_t* ids,
+                                                                     int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx,
+                                                                     int32_t* ticket, int B, int max_len) {
+    __shared__ uint64_t sm[4];
+    const int b = blockIdx.x;
+    const int64_t s = step_idx[0];
+    const uint64_t* row = part + (int64_t)b * n_tiles;
+    uint64_t best = 0;
+    constexpr int UA = 8;      // all loads of a thread in flight together: one round trip for up to 2048 tiles per pass
+    for (int c0 = threadIdx.x; c0 < n_tiles; c0 += 256 * UA) {
+        uint64_t v[UA];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int c = c0 + u * 256;
+            v[u] = c < n_tiles ? row[c] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < UA; ++u) best = v[u] > best ? v[u] : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t ob = shfl_xor_u64_ew(best, o);
+        best = ob > best ? ob : best;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = sm[w] > best ? sm[w] : best;
+        const int64_t id = (int64_t)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));
+        ids[b] = id;
+        if (s < max_len) pred_ids[s * B + b] = id;
+        if (s + 1 < max_len) in_ids[(s + 1) * B + b] = id;
+        slot[b] += 1; pos[b] += 1; kv_len[b] += 1;
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == B - 1) {
+            step_idx[0] = s + 1;
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+extern "C" int umv_decode_step_end_argmax(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const uint64_t* argmax_partial, int n_tiles,
+                                          int64_t* ids, int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int32_t* ticket, int B,
+                                          int max_len, umv_stream_t stream) {
+    UMV_CHECK(tok_slot && tok_pos && kv_len && argmax_partial && ids && in_ids && pred_ids && step_idx && ticket && max_len > 0 && n_tiles > 0,
+              UMV_ERR_ARG, "decode_step_end_argmax: bad args");
+    if (B == 0) return UMV_OK;
+    hipLaunchKernelGGL(decode_step_end_argmax_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tok_slot, tok_pos, kv_len, argmax_partial,
+                       n_tiles, ids, in_ids, pred_ids, step_idx, ticket, B, max_len);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }

@@ -351,12 +351,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
             int m = mb * 16 + (l & 15);
             int n0 = (nt0 + t) * TH + (l >> 4) * 4;
             int nend = min(a.N, (nt0 + t) * TH + TH);            // rows of this tile stop at TH
-            if (m < a.M && n0 < nend) {
+            const bool valid = m < a.M && n0 < nend;
+            float fin[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
                 int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
                 EpiCtx et = e;
                 et.N = nend;
-                epi_store4(et, orow, n0, s.x, s.y, s.z, s.w);
+                epi_store4(et, orow, n0, s.x, s.y, s.z, s.w, fin);
             }
+            if (a.argmax_partial && nt0 + t < NTT)   // wave-uniform: greedy argmax rides on the lm_head epilogue
+                epi_argmax_tile(a.argmax_partial, NTT, m, nt0 + t, l, valid, n0, nend, fin);
         }
     }
 }
@@ -608,10 +612,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
             for (int w = 0; w < SK_WAVES; ++w) s += reinterpret_cast<f32x4*>(red)[(w * E4 + f) * 64 + l];
             int m = mb * 16 + (l & 15);
             int n0 = (nt0 + t) * 16 + (l >> 4) * 4;
-            if (m < a.M && n0 < a.N) {
+            const bool valid = m < a.M && n0 < a.N;
+            float fin[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
                 int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
-                epi_store4(e, orow, n0, s.x, s.y, s.z, s.w);
+                epi_store4(e, orow, n0, s.x, s.y, s.z, s.w, fin);
             }
+            if (a.argmax_partial && nt0 + t < NTT)
+                epi_argmax_tile(a.argmax_partial, NTT, m, nt0 + t, l, valid, n0, a.N, fin);
         }
     }
 }
@@ -641,6 +649,8 @@ extern "C" int umv_gemm_fp8w(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(!a.norm_w && (a.tile_rows == 0 || a.tile_rows == 16), UMV_ERR_UNSUPPORTED, "gemm_fp8w: no fused norm / th-row tiles");
     UMV_CHECK(a.k_splits <= 1 || (!(a.epilogue & UMV_EPI_SWIGLU) && a.split_stride > 0 && a.k_splits <= 64), UMV_ERR_UNSUPPORTED,
               "gemm_fp8w: split-K (k_splits=%d) needs no SwiGLU, split_stride > 0, k_splits <= 64", a.k_splits);
+    UMV_CHECK(!a.argmax_partial || (a.k_splits <= 1 && !a.row_idx && !(a.epilogue & (UMV_EPI_SWIGLU | UMV_EPI_OUT_F32))), UMV_ERR_UNSUPPORTED,
+              "gemm_fp8w: argmax_partial needs bf16 out, no SwiGLU / split-K / row_idx");
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT8 = (a.K + 63) / 64, NTT = (a.N + 15) / 16;
@@ -991,6 +1001,10 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
               UMV_ERR_UNSUPPORTED, "gemm: split-K (k_splits=%d) is a decode mode: M <= 64, 16-row image, no SwiGLU / fused norm, "
               "split_stride > 0", a.k_splits);
     UMV_CHECK(a.k_splits <= 64, UMV_ERR_ARG, "gemm: k_splits %d > 64", a.k_splits);
+    UMV_CHECK(!a.argmax_partial || (a.M <= 64 && a.k_splits <= 1 && !a.row_idx && !a.norm_w && (a.tile_rows == 0 || a.tile_rows == 16) &&
+                                    !(a.epilogue & (UMV_EPI_SWIGLU | UMV_EPI_OUT_F32))),
+              UMV_ERR_UNSUPPORTED, "gemm: argmax_partial is an epilogue of the decode lm_head GEMM (M <= 64, 16-row image, bf16 out, "
+              "no SwiGLU / split-K / row_idx / fused norm)");
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 31) / 32;

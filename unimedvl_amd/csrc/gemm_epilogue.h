@@ -41,8 +41,45 @@ struct EpiCtx {
     int flags;
 };
 
-// Finish 4 consecutive n (n0..n0+3) of row `orow` from fp32 accumulators.
-__device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0, float v0, float v1, float v2, float v3) {
+// Greedy argmax as an epilogue of the lm_head GEMM (bagel.py:1295-1301: argmax over the bf16 logits): every 16-column tile
+// leaves one 64-bit key per row - (order-preserving image of the bf16 logit) << 32 | (0xFFFFFFFF - column) - so that the
+// maximum key is the largest logit and, among equal logits, the LOWEST column (torch.argmax's tie rule; NaN ranks highest
+// like torch).  umv_decode_step_end_argmax takes the maximum over the tiles.
+__device__ __forceinline__ uint64_t argmax_key(float v, int n) {
+    uint32_t b = __float_as_uint(v == 0.f ? 0.f : v);            // -0 == +0
+    uint32_t k = (v != v) ? 0xFFFFFFFFu : ((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+    return ((uint64_t)k << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)n);
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl_xor((int)lo, mask, 64);
+    hi = (uint32_t)__shfl_xor((int)hi, mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// The lane holds columns n0..n0+3 of row m of tile `tile` (lanes l, l^16, l^32, l^48 share the row): reduce the tile's 16
+// columns and let the first lane group write partial[m][tile].  `final` are the values epi_store4 stored (bf16-exact).
+// Must be called by ALL lanes of the wave (shuffles); lanes without a valid element pass valid = false.
+__device__ __forceinline__ void epi_argmax_tile(uint64_t* __restrict__ partial, int64_t ld_partial, int m, int tile, int lane, bool valid,
+                                                int n0, int nend, const float* final) {
+    uint64_t key = 0;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + j < nend) {
+                const uint64_t kj = argmax_key(final[j], n0 + j);
+                key = kj > key ? kj : key;
+            }
+    }
+    uint64_t o = shfl_xor_u64(key, 16);
+    key = o > key ? o : key;
+    o = shfl_xor_u64(key, 32);
+    key = o > key ? o : key;
+    if (valid && (lane >> 4) == 0) partial[(int64_t)m * ld_partial + tile] = key;
+}
+
+// Finish 4 consecutive n (n0..n0+3) of row `orow` from fp32 accumulators.  `final` (optional) receives the stored values.
+__device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0, float v0, float v1, float v2, float v3,
+                                           float* final = nullptr) {
     float v[4] = {v0, v1, v2, v3};
     if (e.flags & UMV_EPI_BIAS) {
 #pragma unroll
@@ -71,6 +108,10 @@ __device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (n0 + j < e.N) v[j] = rbf(v[j] + bf2f(rr[j]));
+    }
+    if (final) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) final[j] = v[j];     // already bf16-exact (every branch above ends in rbf)
     }
     bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + n0;
     if (n0 + 3 < e.N && (((e.ldo | n0) & 3) == 0)) {   // 8-byte aligned: one packed store

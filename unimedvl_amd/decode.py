@@ -79,6 +79,12 @@ class DecodeSession:
         self.act = torch.empty((B, cfg.inter), dtype=BF16, device=dev)
         self.hn = torch.empty((B, H), dtype=BF16, device=dev)
         self.logits = torch.empty((B, cfg.vocab), dtype=BF16, device=dev)
+        # greedy: the argmax rides on the lm_head epilogue (one key per 16-column tile and row) and is finished by the
+        # step-end kernel - the separate 25 us argmax launch over the logits is gone (UMV_DECODE_FUSED_ARGMAX=0 restores it)
+        self.fused_argmax = (not do_sample) and B <= 64 and os.environ.get("UMV_DECODE_FUSED_ARGMAX", "1") not in ("0", "")
+        if self.fused_argmax:
+            self.amax_part = torch.zeros((B, (cfg.vocab + 15) // 16), dtype=torch.int64, device=dev)
+            self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         w = llm.w
         # K splits of the QKV / o / down GEMMs: "q,o,d" (1 = that GEMM is not split), "0" = none, "auto" by batch / weights.
         # Measured on MI355X (bench.py --batch B, ms per step), no split -> 3,4,4:
@@ -168,6 +174,12 @@ class DecodeSession:
             else:
                 ops.gemm(self.act, down_w, out=self.seq, residual=self.seq)
                 ops.rmsnorm(self.seq, nxt, cfg.rms_eps, out=dst)
+        if self.fused_argmax:
+            ops.gemm(self.hn, w.lm_head, out=self.logits, argmax_partial=self.amax_part)
+            # ids = argmax; pred_ids[step] = in_ids[step + 1] = ids; slot / position / kv_len / step += 1: one launch
+            ops.decode_step_end_argmax(self.tok_slot, self.tok_pos, self.kv_len, self.amax_part, self.ids, self.in_ids, self.pred_ids,
+                                       self.step_idx, self.ticket)
+            return
         ops.gemm(self.hn, w.lm_head, out=self.logits)
         if self.do_sample:
             ops.sample(self.logits, self.temperature, self.seed, step=self.step_idx, out=self.ids)

@@ -218,11 +218,12 @@ def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_b
 
 
 def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
-         norm_w=None, norm_eps=1e-6, act8=False):
+         norm_w=None, norm_eps=1e-6, act8=False, argmax_partial=None):
     """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
     norm_w: fuse Qwen2RMSNorm(x)*norm_w into the GEMM prologue (M <= 16, K <= 4096).
     act8 (W8A8 mode, needs lin.w8m): the activations are rounded per row through e4m3 - on the fp8 matrix instruction for
-    M > 64 rows, as a bf16 copy of the rounded rows for the weight-streaming kernels below that."""
+    M > 64 rows, as a bf16 copy of the rounded rows for the weight-streaming kernels below that.
+    argmax_partial (int64 [M, ceil(N/16)], M <= 64): greedy-argmax keys per 16-column tile, finished by decode_step_end_argmax."""
     lib = _lib.load()
     _req(x, BF16, "x")
     assert x.stride(-1) == 1
@@ -251,6 +252,12 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         raise _lib.UmvError("act8 needs a linear with the fp8-MFMA image (enable_fp8_mfma)")
     if act8 and M <= 64:
         x = fake_quantize_act(x, M, row_idx)
+    amax = None
+    if argmax_partial is not None:
+        _req(argmax_partial, torch.int64, "argmax_partial")
+        if not (argmax_partial.is_contiguous() and tuple(argmax_partial.shape) == (M, (lin.N + 15) // 16)):
+            raise _lib.UmvError(f"argmax_partial must be a contiguous int64 [{M}, {(lin.N + 15) // 16}] tensor")
+        amax = argmax_partial.data_ptr()
     # which kernel family takes the call (mirrors the branches below exactly, so a dropped image raises instead of crashing)
     use_a8 = act8 and M > 64 and norm_w is None and not out_f32       # fp8 matrix instruction, e4m3 activations
     use_w8 = lin.w8 is not None and M <= 64 and norm_w is None        # weight-streaming kernel on the e4m3 image
@@ -282,7 +289,7 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
             out=out.data_ptr(), ldo=out.stride(0),
             row_idx=row_idx.data_ptr() if row_idx is not None else None,
             M=M, N=lin.N, K=lin.K, epilogue=flags, norm_w=None, norm_eps=norm_eps, tile_rows=0,
-            w_scale=lin.scale.data_ptr())
+            w_scale=lin.scale.data_ptr(), argmax_partial=amax)
         check(lib.umv_gemm_fp8w(C.byref(a), _stream()), "umv_gemm_fp8w")
         return out
     a = GemmArgs(
@@ -293,7 +300,7 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         out=out.data_ptr(), ldo=out.stride(0),
         row_idx=row_idx.data_ptr() if row_idx is not None else None,
         M=M, N=lin.N, K=lin.K, epilogue=flags,
-        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th)
+        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th, argmax_partial=amax)
     check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
     return out
 
@@ -532,6 +539,21 @@ def decode_step_end(tok_slot, tok_pos, kv_len, ids, in_ids, pred_ids, step_idx):
         raise _lib.UmvError("decode_step_end: in_ids / pred_ids must be contiguous [max_len, B]")
     check(lib.umv_decode_step_end(_p(tok_slot), _p(tok_pos), _p(kv_len), _p(ids), _p(in_ids), _p(pred_ids), _p(step_idx),
                                   ids.numel(), in_ids.shape[0], _stream()), "umv_decode_step_end")
+
+
+def decode_step_end_argmax(tok_slot, tok_pos, kv_len, argmax_partial, ids, in_ids, pred_ids, step_idx, ticket):
+    """ids = argmax over the per-tile keys the lm_head GEMM left in argmax_partial, then decode_step_end's bookkeeping."""
+    lib = _lib.load()
+    for t, name in ((argmax_partial, "argmax_partial"), (ids, "ids"), (in_ids, "in_ids"), (pred_ids, "pred_ids"), (step_idx, "step_idx")):
+        _req(t, torch.int64, name)
+    _req(ticket, torch.int32, "ticket")
+    B = ids.numel()
+    if not (in_ids.is_contiguous() and pred_ids.is_contiguous() and in_ids.shape == pred_ids.shape and in_ids.shape[1] == B
+            and argmax_partial.is_contiguous() and argmax_partial.shape[0] == B):
+        raise _lib.UmvError("decode_step_end_argmax: in_ids / pred_ids [max_len, B], argmax_partial [B, n_tiles], all contiguous")
+    check(lib.umv_decode_step_end_argmax(_p(tok_slot), _p(tok_pos), _p(kv_len), _p(argmax_partial), argmax_partial.shape[1], _p(ids),
+                                         _p(in_ids), _p(pred_ids), _p(step_idx), _p(ticket), B, in_ids.shape[0], _stream()),
+          "umv_decode_step_end_argmax")
 
 
 def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img, renorm_min, rtype, dt):
