@@ -971,10 +971,10 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
 // UMV_GEMM_TILE=<256|266|258|268|129|130|270|64> overrides (tuning only).
 // Exported so that tests can assert which kernel a shape is sent to (returns 0 for M <= 64: weight-streaming kernels).
 extern "C" int umv_gemm_tile_config(int M, int N, int K) {
-    if (M <= 64) return 0;
     static int force = -1;
     if (force < 0) { const char* e = getenv("UMV_GEMM_TILE"); force = e ? atoi(e) : 0; }
     if (force) return force;
+    if (M <= 64) return 0;
     const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long wg258 = (long)((M + 127) / 128) * ((N + 255) / 256);
@@ -1021,7 +1021,13 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // (two n-tiles per workgroup at M <= 8 - twice the workgroups, 216-224 is less than one per CU - measured 3.199 vs
         // 3.176 ms per step: no)
         if (a.M <= 16) return launch_skinny<1, 4, 2, true, 0>(a, KT, NTT, s);
-        if (a.M <= 32) return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
+        if (a.M <= 32) {
+            static int v32 = -1;    // tuning only: UMV_SKINNY_M32=<0|1|2>
+            if (v32 < 0) { const char* e = getenv("UMV_SKINNY_M32"); v32 = e ? atoi(e) : 0; }
+            if (v32 == 1) return launch_skinny<2, 4, 1, true, 0>(a, KT, NTT, s);
+            if (v32 == 2) return launch_skinny<2, 2, 2, true, 0>(a, KT, NTT, s);
+            return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
+        }
         return launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
     }
     if (a.M <= 64 && (a.M <= skinny_max || TH != 16)) {
@@ -1036,11 +1042,30 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         static int nt4 = -1;
         if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : (e && atoi(e) == 8) ? 8 : 1; }
         if (two && nt4 == 8 && TH == 16 && a.M <= 32) return launch_skinny<2, 8, 1, true, 0>(a, KT, NTT, s);
-        if (two && nt4 && TH == 16) return a.M <= 32 ? launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s) : launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
+        if (two && nt4 && TH == 16 && a.M <= 32) {
+            static int v32 = -1;
+            if (v32 < 0) { const char* e = getenv("UMV_SKINNY_M32"); v32 = e ? atoi(e) : 0; }
+            if (v32 == 1) return launch_skinny<2, 4, 1, true, 0>(a, KT, NTT, s);
+            if (v32 == 2) return launch_skinny<2, 2, 2, true, 0>(a, KT, NTT, s);
+            return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
+        }
+        // 33..64 rows on the wide-N GEMMs: the LDS-staged tile 128(n) x 64(m) x 64 reads x once per 128 columns instead of once
+        // per 64 and streams gate/up in 73 us against 84 for the 4-tile skinny kernel (tools/stream_tile_bench.py 64); at
+        // <= 32 rows the skinny kernel wins (60 vs 64-66 us).  Not with the argmax epilogue (skinny kernels only).
+        static int m64 = -1;
+        if (m64 < 0) { const char* e = getenv("UMV_GEMM_M64_TILED"); m64 = e ? atoi(e) : 1; }
+        if (two && TH == 16 && m64 && a.M > 32 && !a.argmax_partial && !a.norm_w && a.K >= 1024) return launch_tiled<4, 1, 2, 4, 2, 3>(a, KT, NTT, s);
+        if (two && nt4 && TH == 16) return launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
     const int cfg = umv_gemm_tile_config(a.M, a.N, a.K);
+    // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)
+    if (cfg == 332) return launch_tiled<4, 1, 2, 2, 4, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 128, 3 buffers (120 KiB), 4 waves
+    if (cfg == 333) return launch_tiled<4, 1, 2, 2, 2, 4>(a, KT, NTT, s);      // 128(n) x 32(m) x 64, 4 buffers (80 KiB)
+    if (cfg == 335) return launch_tiled<4, 1, 2, 2, 2, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 64, 3 buffers (60 KiB, 2 WG/CU)
+    if (cfg == 364) return launch_tiled<4, 1, 2, 4, 2, 3>(a, KT, NTT, s);      // 128(n) x 64(m) x 64, 3 buffers (72 KiB)
+    if (cfg == 3128) return launch_tiled<4, 1, 2, 8, 2, 3>(a, KT, NTT, s);     // 128(n) x 128(m) x 64, 3 buffers (96 KiB)
     if (cfg == 256) return launch_tiled<2, 4, 8, 4, 1, 4>(a, KT, NTT, s);      // 256x256x32, 4 buffers (128 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
