@@ -3,15 +3,16 @@
 same keyword arguments and defaults, same return shapes.
 
 What changes underneath:
-  * contexts are snapshotted by copying only the used part of the KV slabs
-    (NaiveCache.__deepcopy__), and ``gen_text`` decodes on a copy exactly as the reference
-    does (inferencer.py:261), so the caller's context is never advanced by decoding;
+  * the reference's ``deepcopy(gen_context)`` per text item and in ``gen_text`` (inferencer.py:261,587,600,607) is a
+    whole-KV copy; here the three CFG contexts are PREFIX SNAPSHOTS of one in-place cache (kvcache.NaiveCache.snapshot:
+    shared slabs + frozen lengths, copy-on-write), ``cfg_img_context`` gets a prefill of its own only after an image
+    has made its token sequence differ from ``gen_context``'s, and ``gen_text`` decodes in place beyond the committed
+    length and then puts the length back - the caller's context is never advanced by decoding, as in the reference;
   * in understanding mode the reference still prefills the never-used ``cfg_img_context``
     for every text item (inferencer.py:602); that work is skipped when
     ``understanding_output=True`` because nothing ever reads it;
   * all compute runs on the MI355X engine (unimedvl_amd.Bagel).
 """
-from copy import deepcopy
 from typing import Any, Dict, List, Optional, Union
 
 import torch
@@ -61,6 +62,13 @@ class InterleaveInferencer:
     def init_gen_context(self):
         return {"kv_lens": [0], "ropes": [0],
                 "past_key_values": NaiveCache(self.model.config.llm_config.num_hidden_layers)}
+
+    @staticmethod
+    def _snap(ctx):
+        """What the reference gets from ``deepcopy(gen_context)`` (inferencer.py:261,587,600,607), without copying the KV:
+        the snapshot shares the slabs up to the current lengths and copies itself only if IT is written to later
+        (kvcache.NaiveCache.snapshot).  The source context may keep appending."""
+        return {"kv_lens": list(ctx["kv_lens"]), "ropes": list(ctx["ropes"]), "past_key_values": ctx["past_key_values"].snapshot()}
 
     @torch.no_grad()
     def update_context_text(self, text, gen_context):
@@ -126,11 +134,17 @@ class InterleaveInferencer:
 
     @torch.no_grad()
     def gen_text(self, gen_context, max_length: int = 500, do_sample: bool = True, temperature: float = 1.0):
-        gen_context = deepcopy(gen_context)
+        # the reference decodes on a deepcopy so that the context keeps its length (inferencer.py:261); here the decode
+        # appends in place beyond the committed length and the length is simply put back afterwards
+        cache = gen_context["past_key_values"]
         gi = self.model.prepare_start_tokens(gen_context["kv_lens"], gen_context["ropes"], self.new_token_ids)
-        ids = self.model.generate_text(past_key_values=gen_context["past_key_values"], max_length=max_length,
-                                       do_sample=do_sample, temperature=temperature,
-                                       end_token_id=self.new_token_ids["eos_token_id"], **gi)
+        lens0 = list(cache.lens)
+        try:
+            ids = self.model.generate_text(past_key_values=cache, max_length=max_length, do_sample=do_sample,
+                                           temperature=temperature, end_token_id=self.new_token_ids["eos_token_id"], **gi)
+        finally:
+            if cache.slabs is not None:
+                cache.lens = lens0
         output = self.tokenizer.decode(ids[:, 0].cpu())
         return output.split("<|im_end|>")[0].split("<|im_start|>")[1]
 
@@ -145,25 +159,32 @@ class InterleaveInferencer:
         output_list = []
         need_cfg = not understanding_output
         gen_context = self.init_gen_context()
-        cfg_text_context = deepcopy(gen_context)
-        cfg_img_context = deepcopy(gen_context)
+        # The three contexts of inferencer.py:587-607 share prefixes: cfg_text is gen_context as it was before the latest
+        # text item, cfg_img is gen_context without the images.  The reference deep-copies / re-prefills them; here they are
+        # snapshots of gen_context's in-place cache, and cfg_img only gets a prefill of its own once an image has made
+        # the two token sequences differ (until then it IS gen_context's prefix: same tokens, same positions).
+        cfg_text_context = self._snap(gen_context)
+        cfg_img_context = self._snap(gen_context)
+        img_in_sync = True            # cfg_img_context holds exactly gen_context's tokens so far
         if think:
             system_prompt = VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT
             gen_context = self.update_context_text(system_prompt, gen_context)
             if need_cfg:
-                cfg_img_context = self.update_context_text(system_prompt, cfg_img_context)
+                cfg_img_context = self._snap(gen_context)
         for input_term in input_lists:
             if isinstance(input_term, str):
                 if need_cfg:
-                    cfg_text_context = deepcopy(gen_context)
+                    cfg_text_context = self._snap(gen_context)
                 gen_context = self.update_context_text(input_term, gen_context)
                 if need_cfg:
-                    cfg_img_context = self.update_context_text(input_term, cfg_img_context)
+                    cfg_img_context = (self._snap(gen_context) if img_in_sync
+                                       else self.update_context_text(input_term, cfg_img_context))
             elif isinstance(input_term, Image.Image):
                 input_term = self.vae_transform.resize_transform(pil_img2rgb(input_term))
                 gen_context = self.update_context_image(input_term, gen_context, vae=not understanding_output)
+                img_in_sync = False
                 if need_cfg:
-                    cfg_text_context = deepcopy(gen_context)
+                    cfg_text_context = self._snap(gen_context)
             else:
                 raise ValueError(f"Unsupported input type: {type(input_term)}")
         if understanding_output:
@@ -193,7 +214,7 @@ class InterleaveInferencer:
         """VQA, then optionally reconstruct every input image from the answer (inferencer.py:282-362)."""
         output_list = []
         vqa_context = self.init_gen_context()
-        vqa_img_context = deepcopy(vqa_context)
+        vqa_img_context = self._snap(vqa_context)
         for input_term in input_lists:
             if isinstance(input_term, str):
                 vqa_context = self.update_context_text(input_term, vqa_context)
@@ -211,9 +232,9 @@ class InterleaveInferencer:
         input_images = [item for item in input_lists if isinstance(item, Image.Image)]
         if not input_images:
             return output_list
-        cfg_text_precontext = deepcopy(vqa_context)
-        cfg_img_precontext = self.update_context_text(vqa_answer, deepcopy(vqa_img_context))
-        full_context = self.update_context_text(vqa_answer, deepcopy(vqa_context))
+        cfg_text_precontext = self._snap(vqa_context)               # [images, question]: a prefix of full_context
+        cfg_img_precontext = self.update_context_text(vqa_answer, vqa_img_context)
+        full_context = self.update_context_text(vqa_answer, vqa_context)   # appended in place (vqa_context is not used again)
         for original_image in input_images:
             w, h = original_image.size
             target = self._calculate_target_size_with_aspect_ratio(w, h)
@@ -250,8 +271,9 @@ class InterleaveInferencer:
             w, h = picture.size
             target = self._calculate_target_size_with_aspect_ratio(w, h)
             resized = self.vae_transform.resize_transform(pil_img2rgb(picture))
-            image_only = self.update_context_image(resized, self.init_gen_context(), vae=True, vit=True)
-            image_and_answer = self.update_context_text(answer, deepcopy(image_only))
+            image_and_answer = self.update_context_image(resized, self.init_gen_context(), vae=True, vit=True)
+            image_only = self._snap(image_and_answer)           # the cfg_text context is the prefix before the answer
+            image_and_answer = self.update_context_text(answer, image_and_answer)
             answer_only = self.update_context_text(answer, self.init_gen_context())
             outputs.append(self.gen_image(
                 target, image_and_answer, cfg_text_precontext=image_only, cfg_img_precontext=answer_only, cfg_text_scale=7.0,
@@ -315,11 +337,16 @@ class InterleaveInferencer:
     @torch.no_grad()
     def gen_text_batch(self, ctx, max_length: int = 500, do_sample: bool = True, temperature: float = 1.0) -> List[str]:
         """gen_text for every sample of a batched context; each answer ends at that sample's own EOS."""
-        ctx = deepcopy(ctx)
+        cache = ctx["past_key_values"]
         eos = self.new_token_ids["eos_token_id"]
         gi = self.model.prepare_start_tokens(ctx["kv_lens"], ctx["ropes"], self.new_token_ids)
-        ids = self.model.generate_text(past_key_values=ctx["past_key_values"], max_length=max_length, do_sample=do_sample,
-                                       temperature=temperature, end_token_id=eos, per_sample_eos=True, **gi).cpu()
+        lens0 = list(cache.lens)
+        try:        # decode in place beyond the committed lengths, then put the lengths back (see gen_text)
+            ids = self.model.generate_text(past_key_values=cache, max_length=max_length, do_sample=do_sample,
+                                           temperature=temperature, end_token_id=eos, per_sample_eos=True, **gi).cpu()
+        finally:
+            if cache.slabs is not None:
+                cache.lens = lens0
         out = []
         for b in range(ids.shape[1]):
             col = ids[:, b]
@@ -375,25 +402,27 @@ class InterleaveInferencer:
             raise ValueError("batched samples must share one item structure (e.g. every sample = [image, text])")
         need_cfg = not understanding_output
         ctx = self._batch_context(n)
-        cfg_text_ctx, cfg_img_ctx = deepcopy(ctx), deepcopy(ctx)
+        cfg_text_ctx, cfg_img_ctx = self._snap(ctx), self._snap(ctx)     # prefix sharing as in interleave_inference
+        img_in_sync = True
         if think:
             sp = VLM_THINK_SYSTEM_PROMPT if understanding_output else GEN_THINK_SYSTEM_PROMPT
             ctx = self._update_batch_text([sp] * n, ctx)
             if need_cfg:
-                cfg_img_ctx = self._update_batch_text([sp] * n, cfg_img_ctx)
+                cfg_img_ctx = self._snap(ctx)
         for j, kind in enumerate(kinds[0]):
             column = [items[j] for items in input_lists]
             if kind == "s":
                 if need_cfg:
-                    cfg_text_ctx = deepcopy(ctx)
+                    cfg_text_ctx = self._snap(ctx)
                 ctx = self._update_batch_text(column, ctx)
                 if need_cfg:
-                    cfg_img_ctx = self._update_batch_text(column, cfg_img_ctx)
+                    cfg_img_ctx = self._snap(ctx) if img_in_sync else self._update_batch_text(column, cfg_img_ctx)
             else:
                 column = [self.vae_transform.resize_transform(pil_img2rgb(im)) for im in column]
                 ctx = self._update_batch_image(column, ctx, vae=not understanding_output)
+                img_in_sync = False
                 if need_cfg:
-                    cfg_text_ctx = deepcopy(ctx)
+                    cfg_text_ctx = self._snap(ctx)
         outputs = [[] for _ in range(n)]
         if understanding_output:
             for o, t in zip(outputs, self.gen_text_batch(ctx, do_sample=do_sample, temperature=text_temperature,

@@ -24,6 +24,41 @@ class NaiveCache:
         self.lens = []             # committed tokens per segment (host ints)
         self.nkv = self.hd = None
         self.device = None
+        self._borrowed = False     # slabs belong to another cache (snapshot()): copy before the first write
+
+    # --- prefix sharing ("prefix-sharing of the three CFG contexts instead of deepcopy")
+    def snapshot(self):
+        """O(1) logical copy: shares this cache's slabs and freezes the current lengths.  Safe because tokens are only ever
+        APPENDED in place beyond `lens` (this cache may go on appending or decoding; the snapshot never sees those slots)
+        and because a snapshot copies itself before ITS first write (copy-on-write in ensure()).  Replaces the whole-KV
+        ``deepcopy(gen_context)`` the reference takes per text item (inferencer.py:261,587,600,607)."""
+        c = NaiveCache(self._num_layers)
+        c.lens = list(self.lens)
+        c.nkv, c.hd, c.device = self.nkv, self.hd, self.device
+        c.slabs = self.slabs
+        c._borrowed = self.slabs is not None
+        return c
+
+    def shares_storage_with(self, other):
+        """True when both caches read the same slab memory (one is a snapshot of the other, or both of a third)."""
+        if self.slabs is None or other.slabs is None or len(self.slabs) != len(other.slabs):
+            return False
+        return all(a.k.data_ptr() == b.k.data_ptr() and a.vt.data_ptr() == b.vt.data_ptr() and a.cap == b.cap
+                   for a, b in zip(self.slabs, other.slabs))
+
+    def _materialize(self, need_cap):
+        """private copy of the visible prefix (what deepcopy would have made when the snapshot was taken)"""
+        nseg = len(self.lens)
+        cap = _round_up(max(need_cap, self.slabs[0].cap if self.slabs else 0, 256), 256)
+        keep = _round_up(max(max(self.lens), 1), 32)
+        new = []
+        for old in self.slabs:
+            s = ops.KVSlab(nseg, self.nkv, cap, self.hd, self.device)
+            s.k[:, :, :keep].copy_(old.k[:, :, :keep])
+            s.vt[:, :, :, :keep].copy_(old.vt[:, :, :, :keep])
+            new.append(s)
+        self.slabs = new
+        self._borrowed = False
 
     # --- reference-compatible surface
     @property
@@ -69,6 +104,8 @@ class NaiveCache:
             return
         if nseg != len(self.lens):
             raise ValueError(f"cache holds {len(self.lens)} samples, call has {nseg}")
+        if self._borrowed:          # every forward / decode calls ensure() before it writes: copy-on-write happens here
+            self._materialize(need_cap)
         if need_cap > self.cap:
             cap = _round_up(max(need_cap, 2 * self.cap), 256)
             keep = max(self.lens)
@@ -109,6 +146,8 @@ class NaiveCache:
 
     def view_segments(self, start, end):
         """A cache over segments [start, end) sharing this cache's memory (no copy)."""
+        if self._borrowed:
+            self._materialize(self.cap)
         v = NaiveCache(self._num_layers)
         v.lens = list(self.lens[start:end])
         v.nkv, v.hd, v.device = self.nkv, self.hd, self.device
