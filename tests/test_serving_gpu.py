@@ -64,3 +64,26 @@ def test_batcher_rejects_oversized_requests(model):
     srv.submit(None, " ".join(["7"] * 40))
     with pytest.raises(ValueError, match="max_context"):
         srv.run()
+
+
+@pytest.mark.parametrize("slots,check_every", [(4, 3), (8, 4)])
+def test_batched_admission_matches_single_requests(model, slots, check_every):
+    """requests with the same item structure (one image + a prompt) that are admitted in the same round are prefilled by ONE
+    packed ViT + LLM forward into their (non-contiguous) slots while the other slots keep decoding; every answer must equal
+    the one-request-at-a-time answer (bagel.py:1321-1392 per request)."""
+    from oracle.toy_tokenizer import ToyTokenizer
+    from unimedvl_amd.serving import ContinuousBatcher
+    tok = ToyTokenizer(NEW_TOKEN_IDS)
+    g = torch.Generator().manual_seed(33)
+    sizes = [(42, 56), (28, 70), (56, 56), (42, 42), (56, 28), (28, 28), (70, 28), (42, 70), (56, 42), (28, 56), (42, 28)]
+    reqs = [([torch.randn(3, h, w, generator=g).clamp(-1, 1)], " ".join(str(int(v)) for v in torch.randint(5, 290, (2 + i % 5,), generator=g)))
+            for i, (h, w) in enumerate(sizes)]
+    budgets = [6, 2, 5, 2, 6, 3, 2, 6, 4, 2, 5]         # several slots finish in the same round -> batched refills
+    ident = lambda x: x   # noqa: E731
+    want = [model.chat(tok, NEW_TOKEN_IDS, ident, images, prompt, max_length=nb + 1) for (images, prompt), nb in zip(reqs, budgets)]
+    srv = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, ident, slots=slots, max_context=256, max_new_tokens=8, check_every=check_every)
+    rids = [srv.submit(images, prompt, max_new_tokens=nb) for (images, prompt), nb in zip(reqs, budgets)]
+    got = srv.run()
+    for rid, w in zip(rids, want):
+        assert got[rid] == w, (rid, got[rid], w)
+    assert srv.stats["prefills"] == len(reqs) and srv.stats.get("batched_prefills", 0) >= 2

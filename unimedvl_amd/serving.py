@@ -73,10 +73,13 @@ class ContinuousBatcher:
         active: List[Optional[_Request]] = [None] * B
         state = [(bos, 0, 0)] * B                       # (next token, kv_len, rope position) per slot
         cache.lens = [0] * B
+        first = []
         for b in range(B):
             if self.queue:
                 active[b] = self.queue.popleft()
-                state[b] = self._prefill(b, active[b])
+                first.append(b)
+        for b, st in zip(first, self._prefill_many(first, [active[b] for b in first])):
+            state[b] = st
         start = torch.tensor([s[0] for s in state], dtype=torch.int64)
         pos = torch.tensor([s[2] for s in state], dtype=torch.int64)
         seed = m._sampling_seed() if self.do_sample else 0
@@ -90,6 +93,7 @@ class ContinuousBatcher:
             sess.step(k)
             self.stats["decode_steps"] += k
             ids = sess.pred_ids[:k].cpu()               # [k, B]; the only host sync of the round
+            freed = []
             for b in range(B):
                 req = active[b]
                 if req is None:
@@ -112,10 +116,13 @@ class ContinuousBatcher:
                 cache.lens[b] = 0
                 if self.queue:
                     active[b] = self.queue.popleft()
-                    tok, kvl, rope = self._prefill(b, active[b])
-                    sess.set_slot(b, tok, kvl, rope)
+                    freed.append(b)
                 else:
                     sess.set_slot(b, bos, 0, 0)
+            # every slot that was freed this round is refilled by ONE batched prefill (images of the new requests share the
+            # ViT and LLM forward; the other slots take part with zero query tokens)
+            for b, (tok, kvl, rope) in zip(freed, self._prefill_many(freed, [active[b] for b in freed])):
+                sess.set_slot(b, tok, kvl, rope)
         return dict(self.results)
 
     # ------------------------------------------------------------------ internals
@@ -138,6 +145,47 @@ class ContinuousBatcher:
         self.cache.lens[b] = view.lens[0]
         self.stats["prefills"] += 1
         return (self.new_token_ids["bos_token_id"], view.lens[0], rope[0])
+
+    def _prefill_many(self, slots: List[int], reqs: List[_Request]):
+        """Prefill several newly admitted requests together (slots ascending): image j of every request goes through one
+        ViT + one packed LLM forward over the WHOLE slot cache, in which the other slots are segments with zero query
+        tokens (their keys are not touched: the kernels address the cache by per-token segment / slot indices and skip
+        segments without queries).  Falls back to one prefill per request when the requests' image counts differ."""
+        if not slots:
+            return []
+        if len(slots) == 1 or len({len(r.images) for r in reqs}) != 1:
+            return [self._prefill(b, r) for b, r in zip(slots, reqs)]
+        m, cache, B = self.model, self.cache, self.slots
+        cap = cache.cap
+        for b in slots:
+            cache.lens[b] = 0
+        k = len(slots)
+        kvl, rope = [0] * k, [0] * k
+
+        def spread(per_request):          # [k] query lengths -> [B] with zeros for the slots that do not take part
+            full = torch.zeros(B, dtype=per_request.dtype)
+            full[torch.tensor(slots)] = per_request.cpu()
+            return full
+        for j in range(len(reqs[0].images)):
+            gi, kvl, rope = m.prepare_vit_images(kvl, rope, [r.images[j] for r in reqs], self.image_transform, self.new_token_ids)
+            for n, r in zip(kvl, reqs):
+                self._check_room(n, r, cap)
+            gi["packed_seqlens"] = spread(gi["packed_seqlens"])
+            gi["key_values_lens"] = gi["packed_key_value_indexes"] = gi["packed_indexes"] = None   # written for a k-sample cache
+            m.forward_cache_update_vit(cache, **gi)
+        gi, kvl, rope = m.prepare_prompts(kvl, rope, [r.prompt for r in reqs], self.tokenizer, self.new_token_ids)
+        for n, r in zip(kvl, reqs):
+            self._check_room(n, r, cap)
+        gi["text_token_lens"] = spread(gi["text_token_lens"])
+        gi["key_values_lens"] = gi["packed_key_value_indexes"] = gi["packed_text_indexes"] = None
+        m.forward_cache_update_text(cache, **gi)
+        if cache.cap != cap:
+            raise RuntimeError("the slot cache was re-allocated: a request does not fit the reserved capacity")
+        for b, n in zip(slots, kvl):
+            assert cache.lens[b] == n
+        self.stats["prefills"] += k
+        self.stats["batched_prefills"] = self.stats.get("batched_prefills", 0) + 1
+        return [(self.new_token_ids["bos_token_id"], n, r) for n, r in zip(kvl, rope)]
 
     def _check_room(self, ctx_tokens: int, req: _Request, cap: int):
         if ctx_tokens > self.max_context or ctx_tokens + req.max_new_tokens + self.check_every + 1 > cap:
