@@ -120,7 +120,7 @@ def _forced_decode_check(model, oracle, cache, ocache, kvl, rope, ntid, steps, w
         cos = torch.nn.functional.cosine_similarity(lg, ref, dim=-1).min().item()
         assert cos > 0.999, f"{what}: logits cosine {cos} at step {s}"
         top2 = ref.topk(2, dim=-1).values
-        sure = (top2[:, 0] - top2[:, 1]) > 0.25
+        sure = (top2[:, 0] - top2[:, 1]) > (0.25 if atol <= 0.25 else 2 * atol)
         pred, ref_pred = sess.pred_ids[s].cpu(), ref.argmax(-1)
         assert torch.equal(lg.argmax(-1), pred), f"{what}: device argmax disagrees with the logits it was taken from (step {s})"
         assert torch.equal(pred[sure], ref_pred[sure]), f"{what}: greedy id differs at step {s} despite a top-2 margin > 0.25"
@@ -248,3 +248,53 @@ def test_configs2_t2i_256_guided_flow_and_pixels(fw):
                 f"pixels sample {b}: {100 * (diff <= 4).float().mean().item():.2f}% within 4 levels, max {diff.max().item()}"
     assert gen.lens == cfg_img.lens == kvl and cfg_text.seq_lens == 0, "flow passes must not commit KV"
     print(f"configs[2] B=4 256x256: worst latent deviation over {steps - 1} Euler steps {worst:.4f}")
+
+
+@pytest.mark.parametrize("act8", [False, True])
+def test_configs4_fp8_weights_fullwidth(fw, act8):
+    """configs[4]: e4m3 LLM weights at full width.  PARITY UNPINNED BY THE REFERENCE (it has no fp8 path): the checker is
+    the bf16 oracle on the DEQUANTISED weights (oracle/fp8.py: W' = q * 2^e is exact in bf16), in W8A8 mode with the linear
+    inputs of every non-decode forward rounded per row through e4m3.  act8=False: weight-only (decode streams the e4m3
+    image through gemm_skinny8, prefill runs the bf16 tiled kernel on W') at the bf16 tolerances; act8=True: prefill on the
+    fp8 matrix instruction (gemm_tiled8) at the W8A8 bounds of tests/test_fp8_gpu.py (a rounding step of e4m3 is 2^-3
+    relative, so one bf16 ulp upstream can move an activation by a whole step)."""
+    from oracle import fp8
+    from oracle.unimedvl_cpu import KVCache, OracleBagel
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.kvcache import NaiveCache
+    model, vae, oracle, cfg, ntid = fw
+    sd_cpu = oracle.sd
+    cfg8 = UniMedVLConfig.from_dict(cfg.to_dict())
+    cfg8.llm_weight_dtype = "fp8"
+    cfg8.llm_act_dtype = "fp8" if act8 else "bf16"
+    m8 = Bagel(cfg8, lambda n: sd_cpu[n], device=model.device, visual_gen=False, visual_und=True)
+    w = m8.language_model.w
+    assert w.fp8 and w.und[0].gate_up.w8 is not None and (w.und[0].qkv.w8m is not None) == act8
+    if not hasattr(test_configs4_fp8_weights_fullwidth, "_deq"):     # 2 G weights through the CPU quantiser: once
+        test_configs4_fp8_weights_fullwidth._deq = fp8.dequantised_weights(sd_cpu)
+    o8 = OracleBagel(cfg.to_dict(), test_configs4_fp8_weights_fullwidth._deq, None, attn_impl="flash", act_fp8=act8)
+    B = 4
+    images = [_synth_image(448, 448, 300 + i) for i in range(B)]
+    prompts = _prompts([32] * B, 9)
+    cache = NaiveCache(cfg.layers)
+    gi, kvl, rope = m8.prepare_vit_images([0] * B, [0] * B, images, lambda x: x, ntid)
+    cache = m8.forward_cache_update_vit(cache, **gi)
+    gi, kvl, rope = m8.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTok(prompts), ntid)
+    cache = m8.forward_cache_update_text(cache, **gi)
+    oc = KVCache(cfg.layers, B)
+    okv, orope = o8.update_vit(oc, [0] * B, [0] * B, images, ntid)
+    okv, orope = o8.update_text(oc, okv, orope, [[ntid["bos_token_id"]] + p + [ntid["eos_token_id"]] for p in prompts])
+    assert okv == kvl and orope == rope
+    if not act8:
+        _check_kv(cache, oc, range(cfg.layers), 2e-2, "fp8 weights, after prefill")
+        _forced_decode_check(m8, o8, cache, oc, kvl, rope, ntid, 12, "configs[4] fp8 weights B=4")
+    else:
+        L = cfg.layers
+        kref, kgot = torch.cat(oc.k[L - 1], 0).float(), cache.packed_keys(L - 1).float().cpu()
+        rel = ((kgot - kref).norm() / kref.norm()).item()
+        print(f"W8A8 full width: last-layer keys rel fro {rel:.4f}")
+        assert rel <= 0.06, f"W8A8 last-layer keys: relative Frobenius error {rel}"
+        _forced_decode_check(m8, o8, cache, oc, kvl, rope, ntid, 12, "configs[4] W8A8 B=4", atol=0.5)
+    del m8
+    torch.cuda.empty_cache()
