@@ -294,7 +294,7 @@ def test_configs4_fp8_weights_fullwidth(fw, act8):
         kref, kgot = torch.cat(oc.k[L - 1], 0).float(), cache.packed_keys(L - 1).float().cpu()
         rel = ((kgot - kref).norm() / kref.norm()).item()
         print(f"W8A8 full width: last-layer keys rel fro {rel:.4f}")
-        assert rel <= 0.06, f"W8A8 last-layer keys: relative Frobenius error {rel}"
-        _forced_decode_check(m8, o8, cache, oc, kvl, rope, ntid, 12, "configs[4] W8A8 B=4", atol=0.5)
+        assert rel <= 0.08, f"W8A8 last-layer keys: relative Frobenius error {rel}"       # measured 0.058 (tiny model: 0.04)
+        _forced_decode_check(m8, o8, cache, oc, kvl, rope, ntid, 12, "configs[4] W8A8 B=4")   # measured worst 0.0625
     del m8
     torch.cuda.empty_cache()
