@@ -180,3 +180,23 @@ def test_checkpoint_overlay_and_bf16_preference(tmp_path):
         SafetensorsGetter(str(base / "ema.safetensors"), {"a.weight": (3, 2)})("a.weight")
     with pytest.raises(FileNotFoundError):
         find_weights_file(str(tmp_path / "nothing"))
+
+
+def test_kernel_policy_queries_need_no_gpu():
+    """umv_gemm_tile_config / umv_attn_prefill_tq are host-only: the shape -> kernel policy the GPU branch tests pin
+    (tests/test_kernel_branches_gpu.py) can be read on a machine without a GPU"""
+    from unimedvl_amd import _lib
+    lib = _lib.load()
+    # the bench's prefill / ViT / flow shapes go to the hand-interleaved 256x256 tile
+    for M, N, K in ((8208, 4608, 3584), (8208, 37888, 3584), (8208, 3584, 18944), (8192, 3456, 1152), (2064, 37888, 3584)):
+        assert lib.umv_gemm_tile_config(M, N, K) == 266, (M, N, K)
+    assert lib.umv_gemm_tile_config(1026, 4608, 3584) == 268        # one image span: 256(n) x 128(m)
+    assert lib.umv_gemm_tile_config(1026, 3584, 3584) == 270        # 128 x 128, two workgroups per CU
+    assert lib.umv_gemm_tile_config(300, 1152, 608) == 64           # short K
+    assert lib.umv_gemm_tile_config(8, 37888, 3584) == 0            # M <= 64: weight-streaming kernels
+    # prefill attention: two q-tiles per wave from 512 workgroups on
+    assert lib.umv_attn_prefill_tq(8, 28, 4, 128, 1026) == 2
+    assert lib.umv_attn_prefill_tq(1, 28, 4, 128, 1026) == 1
+    assert lib.umv_attn_prefill_tq(8, 16, 16, 72, 1024) == 2
+    assert lib.umv_attn_prefill_tq(8, 28, 4, 128, 1) == 0           # decode: the per-wave kernel
+    assert lib.umv_attn_prefill_tq(8, 2, 1, 64, 1000) == 0          # head dims without an LDS-shared kernel
