@@ -309,6 +309,11 @@ int umv_decode_step_end_argmax(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_
  * latency-bound kernels of a decode step.  `sink` (4 bytes, may be NULL) only keeps the loads alive. */
 int umv_prefetch(const void* ptr, size_t bytes, int blocks, void* sink, umv_stream_t stream);
 
+/* TimestepEmbedder.timestep_embedding (modeling_utils.py:87-109): out[r] = bf16(cat(cos(t[r] * freqs), sin(t[r] * freqs))),
+ * out [n, 2*half]; freqs [half] fp32 = exp(-ln(10000) * i / half) from the caller.  The two linears + SiLU of the embedder
+ * are umv_gemm_bf16 calls (UMV_EPI_SILU). */
+int umv_timestep_embed(const float* t, const float* freqs, uint16_t* out, int n, int half, umv_stream_t stream);
+
 /* ------------------------------------------------------------------ image head
  * CFG combine + renorm + Euler update (bagel.py:1173-1207, :983), bf16 rounding after each
  * op as the reference's bf16 tensors imply; x_t [N,D] fp32 updated in place.  v_* are

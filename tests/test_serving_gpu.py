@@ -87,3 +87,79 @@ def test_batched_admission_matches_single_requests(model, slots, check_every):
     for rid, w in zip(rids, want):
         assert got[rid] == w, (rid, got[rid], w)
     assert srv.stats["prefills"] == len(reqs) and srv.stats.get("batched_prefills", 0) >= 2
+
+
+def test_image_prefill_graph_equals_eager(model):
+    """the image-span prefill into a RESERVED cache replays from a HIP graph keyed by the patch grid (Bagel._vit_graph_run);
+    K / V and the decoded answer must equal the eager path bit for bit, for a second image of the same size (replay with new
+    pixels), at another cache offset, and in another segment of a multi-slot cache."""
+    from unimedvl_amd.kvcache import NaiveCache
+    cfg = model.cfg
+    g = torch.Generator().manual_seed(44)
+    imgs = [torch.randn(3, 42, 56, generator=g).clamp(-1, 1) for _ in range(3)]
+
+    class Tok:
+        def encode(self, s):
+            return [int(x) for x in s.split()]
+    ident = lambda x: x   # noqa: E731
+
+    def run(cache, images, slot=None, nslots=1):
+        kvl, rope = [0] * nslots, [0] * nslots
+        for im in images:
+            if slot is None:
+                gi, kvl, rope = model.prepare_vit_images(kvl, rope, [im], ident, NEW_TOKEN_IDS)
+            else:       # one image into segment `slot` of a multi-slot cache: the other segments take part with zero tokens
+                gi, k1, r1 = model.prepare_vit_images([kvl[slot]], [rope[slot]], [im], ident, NEW_TOKEN_IDS)
+                full = torch.zeros(nslots, dtype=gi["packed_seqlens"].dtype)
+                full[slot] = gi["packed_seqlens"][0]
+                gi["packed_seqlens"] = full
+                gi["key_values_lens"] = gi["packed_key_value_indexes"] = gi["packed_indexes"] = None
+                kvl[slot], rope[slot] = k1[0], r1[0]
+            cache = model.forward_cache_update_vit(cache, **gi)
+        return cache, kvl, rope
+
+    eager, kvl, rope = run(NaiveCache(cfg.layers), imgs[:2])              # not reserved -> eager kernels
+    assert not model._vit_graphs or True
+    n_before = len(model._vit_graphs)
+    pooled = NaiveCache(cfg.layers)
+    pooled.reserve(1, 512, cfg.kv_heads, cfg.head_dim, model.device)
+    pooled, kvl2, rope2 = run(pooled, imgs[:2])                           # capture at offset 0, replay at offset 14
+    assert len(model._vit_graphs) == n_before + 1, "same patch grid, same cache: one graph serves both offsets"
+    assert kvl2 == kvl and rope2 == rope and pooled.lens == eager.lens
+    for l in range(cfg.layers):
+        assert torch.equal(pooled.packed_keys(l), eager.packed_keys(l)) and torch.equal(pooled.packed_values(l), eager.packed_values(l))
+    gi, kv3, rp3 = model.prepare_prompts(kvl, rope, ["5 6 7"], Tok(), NEW_TOKEN_IDS)
+    a = model.generate_text(past_key_values=model.forward_cache_update_text(eager, **gi), max_length=5,
+                            **model.prepare_start_tokens(kv3, rp3, NEW_TOKEN_IDS))
+    b = model.generate_text(past_key_values=model.forward_cache_update_text(pooled, **gi), max_length=5,
+                            **model.prepare_start_tokens(kv3, rp3, NEW_TOKEN_IDS))
+    assert torch.equal(a, b)
+    # a 4-slot cache: one graph, any slot
+    multi = NaiveCache(cfg.layers)
+    multi.reserve(4, 256, cfg.kv_heads, cfg.head_dim, model.device)
+    multi.lens = [0] * 4
+    n0 = len(model._vit_graphs)
+    multi, _, _ = run(multi, [imgs[2]], slot=2, nslots=4)
+    multi, _, _ = run(multi, [imgs[0]], slot=0, nslots=4)
+    assert len(model._vit_graphs) == n0 + 1
+    one, _, _ = run(NaiveCache(cfg.layers), [imgs[2]])
+    two, _, _ = run(NaiveCache(cfg.layers), [imgs[0]])
+    for l in range(cfg.layers):
+        assert torch.equal(multi.view_segments(2, 3).packed_keys(l), one.packed_keys(l))
+        assert torch.equal(multi.view_segments(0, 1).packed_values(l), two.packed_values(l))
+    assert multi.lens == [one.lens[0] if False else two.lens[0], 0, one.lens[0], 0]
+
+
+def test_chat_with_pooled_cache_equals_plain_chat(model):
+    from oracle.toy_tokenizer import ToyTokenizer
+    tok = ToyTokenizer(NEW_TOKEN_IDS)
+    g = torch.Generator().manual_seed(45)
+    imgs = [torch.randn(3, 56, 42, generator=g).clamp(-1, 1) for _ in range(3)]
+    ident = lambda x: x   # noqa: E731
+    want = [model.chat(tok, NEW_TOKEN_IDS, ident, [im], "9 8 7 6", max_length=6) for im in imgs]
+    model.chat_cache_tokens = 256
+    try:
+        got = [model.chat(tok, NEW_TOKEN_IDS, ident, [im], "9 8 7 6", max_length=6) for im in imgs]
+    finally:
+        model.chat_cache_tokens = 0
+    assert got == want

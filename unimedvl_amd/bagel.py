@@ -64,6 +64,11 @@ class Bagel(BagelPrep):
             max_latent_size=cfg.max_latent, vit_max_num_patch_per_side=cfg.vit_side)
         self.decode_use_graph = True
         self.eos_check_every = 16
+        import os
+        self.prefill_graph = os.environ.get("UMV_PREFILL_GRAPH", "1") not in ("0", "")   # graph replay of image spans into reserved caches
+        self._vit_graphs = {}
+        self.chat_cache_tokens = 0          # > 0: chat() prefills / decodes in one pooled, reserved cache of that capacity
+        self._chat_cache = None
 
     def eval(self):
         return self
@@ -93,6 +98,67 @@ class Bagel(BagelPrep):
         h = ops.gemm(vit, self.glue.conn1, act="gelu_tanh")
         return ops.gemm(h, self.glue.conn2)
 
+    # ---- image-span prefill from a HIP graph
+    # One 448x448 image is ~460 kernel launches (ViT tower, connector, 28 LLM layers over 1026 tokens): 33 ms of GPU work but
+    # ~55 ms of wall time when every launch goes through ctypes.  The shapes depend only on the image's patch grid, and all
+    # per-request values (pixels, which cache segment / slot the tokens go to, rope position, keys visible) are read by the
+    # kernels from device memory, so for a cache whose slabs stay put (NaiveCache.reserve) the whole span is captured once
+    # per (cache, grid) and replayed: the request's pixels and a ~12 KB plan are uploaded, then one graph launch.
+    def _vit_graph_key(self, cache, gi):
+        if not self.prefill_graph or cache is None or not getattr(cache, "reserved", False) or cache.slabs is None:
+            return None
+        lens = [int(v) for v in gi["vit_token_seqlens"].tolist()]
+        if len(lens) != 1:                       # one image per call (the scripts' and the batcher's admission path)
+            return None
+        qlens = [int(v) for v in gi["packed_seqlens"].tolist()]
+        if max(c + q for c, q in zip(cache.lens, qlens)) > cache.cap:
+            return None                          # would re-allocate: the eager path handles (and reports) that
+        pos = gi["packed_vit_position_ids"]
+        return (cache.slabs[0].k.data_ptr(), cache.cap, len(cache.lens), lens[0], int(pos[0]), int(pos[-1]), int(gi["packed_text_ids"][0]),
+                int(gi["packed_text_ids"][-1]))
+
+    def _vit_graph_run(self, key, cache, gi):
+        dev, lm = self.device, self.language_model
+        qlens = [int(v) for v in gi["packed_seqlens"].tolist()]
+        nseg = len(cache.lens)
+        if len(qlens) != nseg:
+            raise ValueError(f"cache holds {nseg} samples, call has {len(qlens)}")
+        cu = torch.nn.functional.pad(torch.cumsum(gi["vit_token_seqlens"].to("cpu"), dim=0), (1, 0)).to(torch.int32)
+        g = self._vit_graphs.get(key)
+        if g is None:
+            g = SimpleNamespace()
+            g.text_ids = gi["packed_text_ids"].to(device=dev, dtype=torch.int64)
+            g.text_rows = gi["packed_text_indexes"].to(device=dev, dtype=torch.int32)
+            g.vit_rows = gi["packed_vit_token_indexes"].to(device=dev, dtype=torch.int32)
+            g.vplan = self.vit_model.make_plan(gi["packed_vit_tokens"], gi["packed_vit_position_ids"], cu, int(gi["vit_token_seqlens"].max()))
+            g.lplan = lm.make_plan(qlens, gi["packed_position_ids"], cache.lens)
+            g.lplan.max_kv = cache.cap
+            T = sum(qlens)
+
+            def body():
+                seq = torch.zeros((T, self.hidden_size), dtype=BF16, device=dev)
+                lm.embed_tokens(g.text_ids, out=seq, out_rows=g.text_rows)
+                vit = self.vit_model(plan=g.vplan)
+                conn = ops.gemm(ops.gemm(vit, self.glue.conn1, act="gelu_tanh"), self.glue.conn2)
+                ops.add_rows(conn, seq, table=self.glue.vit_pos, idx=g.vplan["pos_ids"], out_rows=g.vit_rows)
+                lm.forward_inference(packed_query_sequence=seq, query_lens=g.lplan.qlens, packed_query_position_ids=None,
+                                     past_key_values=cache, update_past_key_values=False, is_causal=False, mode="und", plan=g.lplan)
+            s = torch.cuda.Stream(device=dev)        # warm-up outside the capture (lazy module loading, allocator)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                body()
+            torch.cuda.current_stream().wait_stream(s)
+            g.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.graph):
+                body()
+            self._vit_graphs[key] = g
+        else:
+            self.vit_model.make_plan(gi["packed_vit_tokens"], gi["packed_vit_position_ids"], cu, int(gi["vit_token_seqlens"].max()), into=g.vplan)
+            lm.make_plan(qlens, gi["packed_position_ids"], cache.lens, into=g.lplan)
+        g.graph.replay()
+        cache.lens = [c + q for c, q in zip(cache.lens, qlens)]
+        return cache
+
     @torch.no_grad()
     @ops.on_device
     def forward_cache_update_vit(self, past_key_values: NaiveCache, packed_text_ids, packed_text_indexes,
@@ -100,6 +166,15 @@ class Bagel(BagelPrep):
                                  packed_position_ids, packed_seqlens, packed_indexes=None, packed_key_value_indexes=None,
                                  key_values_lens=None):
         dev = self.device
+        if key_values_lens is not None and past_key_values is not None and past_key_values.slabs is not None and \
+                [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
+            raise ValueError(f"key_values_lens {key_values_lens.tolist()} disagree with the cache ({past_key_values.lens})")
+        gi = dict(packed_text_ids=packed_text_ids, packed_text_indexes=packed_text_indexes, packed_vit_tokens=packed_vit_tokens,
+                  packed_vit_token_indexes=packed_vit_token_indexes, packed_vit_position_ids=packed_vit_position_ids,
+                  vit_token_seqlens=vit_token_seqlens, packed_position_ids=packed_position_ids, packed_seqlens=packed_seqlens)
+        key = self._vit_graph_key(past_key_values, gi)
+        if key is not None:
+            return self._vit_graph_run(key, past_key_values, gi)
         T = int(packed_seqlens.sum())
         seq = torch.zeros((T, self.hidden_size), dtype=BF16, device=dev)
         self.language_model.embed_tokens(packed_text_ids, out=seq,
@@ -117,15 +192,15 @@ class Bagel(BagelPrep):
     # ------------------------------------------------------------------ VAE-encoded images (edit / reconstruction)
     @ops.on_device
     def time_embed(self, t_values):
-        """TimestepEmbedder (modeling_utils.py:87-109) for a vector of timesteps -> [n, hidden] bf16.
-        The 256-wide sinusoid is built on the host in fp32 with torch (same bits as the
-        reference); the two linears and the SiLU run on the GPU."""
+        """TimestepEmbedder (modeling_utils.py:87-109) for a vector of timesteps -> [n, hidden] bf16: the 256-wide sinusoid
+        (umv_timestep_embed; the 128 frequencies come from torch once, so t * freqs has the reference's bits), then the two
+        linears with the SiLU in the first one's epilogue."""
         import math
         half = 128
-        t = torch.as_tensor(t_values, dtype=torch.float32).reshape(-1)
-        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
-        args = t[:, None].float() * freqs[None]
-        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(BF16).to(self.device)
+        if getattr(self, "_t_freqs", None) is None:
+            self._t_freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(self.device)
+        t = torch.as_tensor(t_values, dtype=torch.float32).reshape(-1).to(self.device)
+        emb = ops.timestep_embed(t, self._t_freqs)
         h = ops.gemm(emb, self.glue.time0, act="silu")
         return ops.gemm(h, self.glue.time2)
 
@@ -346,7 +421,14 @@ class Bagel(BagelPrep):
     def chat(self, tokenizer, new_token_ids, image_transform, images, prompt, max_length: int,
              do_sample: bool = False, temperature: float = 1.0):
         """ViT-only VQA convenience path (bagel.py:1321-1392)."""
-        cache = NaiveCache(self.cfg.layers)
+        if self.chat_cache_tokens > 0:       # serving: one reserved cache reused by every request (stable slabs -> graph prefill)
+            if self._chat_cache is None or self._chat_cache.cap < self.chat_cache_tokens:
+                self._chat_cache = NaiveCache(self.cfg.layers)
+                self._chat_cache.reserve(1, self.chat_cache_tokens, self.cfg.kv_heads, self.cfg.head_dim, self.device)
+            cache = self._chat_cache
+            cache.lens = [0]
+        else:
+            cache = NaiveCache(self.cfg.layers)
         newlens, new_rope = [0], [0]
         for image in images:
             gi, newlens, new_rope = self.prepare_vit_images(newlens, new_rope, [image], image_transform, new_token_ids)

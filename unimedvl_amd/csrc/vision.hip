@@ -104,6 +104,28 @@ __global__ __launch_bounds__(1024) void cfg_renorm_euler_kernel(float* __restric
     }
 }
 
+// ----------------------------------------------------------------------------- timestep sinusoid
+// TimestepEmbedder.timestep_embedding (modeling_utils.py:87-109): args = t[:, None] * freqs[None] in fp32,
+// emb = cat(cos(args), sin(args)) cast to bf16 by autocast in front of mlp[0].  `freqs` = exp(-ln(10000) * i / half) comes from
+// the caller (computed once with torch, so t * freqs has the reference's bits); cos / sin are the full-range libm versions.
+__global__ void timestep_embed_kernel(const float* __restrict__ t, const float* __restrict__ freqs, bf16_t* __restrict__ out, int n, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * half) return;
+    const int row = i / half, j = i - row * half;
+    const float a = t[row] * freqs[j];
+    float sn, cs;
+    sincosf(a, &sn, &cs);
+    out[(int64_t)row * 2 * half + j] = f2bf(cs);
+    out[(int64_t)row * 2 * half + half + j] = f2bf(sn);
+}
+extern "C" int umv_timestep_embed(const float* t, const float* freqs, uint16_t* out, int n, int half, umv_stream_t stream) {
+    UMV_CHECK(t && freqs && out && n >= 0 && half > 0, UMV_ERR_ARG, "timestep_embed: bad args");
+    if (n == 0) return UMV_OK;
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((n * half + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, freqs, out, n, half);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
 extern "C" int umv_cfg_renorm_euler(float* x_t, const uint16_t* v_t, const uint16_t* v_text, const uint16_t* v_img, int64_t ldv,
                                     const int32_t* rows, const int32_t* seg_off, int nseg, float cfg_text_scale,
                                     float cfg_img_scale, float renorm_min, int renorm_type, float dt, int D,

@@ -25,6 +25,7 @@ class NaiveCache:
         self.nkv = self.hd = None
         self.device = None
         self._borrowed = False     # slabs belong to another cache (snapshot()): copy before the first write
+        self.reserved = False      # reserve() was called: slab addresses are stable for the life of the cache
 
     # --- prefix sharing ("prefix-sharing of the three CFG contexts instead of deepcopy")
     def snapshot(self):
@@ -119,8 +120,10 @@ class NaiveCache:
             self.slabs = new
 
     def reserve(self, nseg, cap, nkv, hd, device):
-        """Pre-size (bench / serving) so that decode never re-allocates."""
+        """Pre-size (bench / serving) so that decode never re-allocates.  A reserved cache keeps its slab addresses, which is
+        what lets fixed-shape prefills into it replay from a HIP graph (bagel.Bagel.forward_cache_update_vit)."""
         self.ensure(nseg, cap, nkv, hd, device)
+        self.reserved = True
 
     @staticmethod
     def merged(caches, nsegs, extra, nkv, hd, device):

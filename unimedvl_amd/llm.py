@@ -31,6 +31,11 @@ class BaseNavitOutputWithPast:
     past_key_values: Optional[NaiveCache] = None
 
 
+class ForwardPlan:
+    """device-side bookkeeping of one packed forward (Qwen2MoT.make_plan)"""
+    __slots__ = ("buf", "qlens", "max_kv", "tok_seg", "tok_slot", "tok_pos", "cu_q", "kv_len")
+
+
 def _host_list(x):
     if isinstance(x, torch.Tensor):
         return [int(v) for v in x.tolist()]
@@ -64,12 +69,52 @@ class Qwen2MoT:
     def lm_head(self, h):
         return ops.gemm(h, self.w.lm_head)
 
+    # ------------------------------------------------------------------ per-token bookkeeping of one forward
+    @ops.on_device
+    def make_plan(self, qlens, position_ids, cache_lens, into: "ForwardPlan" = None) -> "ForwardPlan":
+        """Everything a forward needs from the host, as device tensors: segment / slot / rope position of every query token,
+        cu_seqlens of the queries, keys visible per segment after the call.  One small upload.  `into` refreshes an
+        existing plan IN PLACE (same device addresses) - what a captured HIP graph of the forward reads at replay."""
+        cfg, dev = self.cfg, self.device
+        qlens = [int(q) for q in qlens]
+        seg, slot = [], []
+        for s, (c, q) in enumerate(zip(cache_lens, qlens)):
+            seg += [s] * q
+            slot += list(range(c, c + q))
+        pos = position_ids.to(dtype=torch.int32).cpu() if isinstance(position_ids, torch.Tensor) else torch.tensor(position_ids, dtype=torch.int32)
+        # the rotary tables hold cfg.max_position rows and the kernels index them unchecked
+        pmax = int(pos.max()) if pos.numel() else 0
+        pmin = int(pos.min()) if pos.numel() else 0
+        if pmin < 0 or pmax >= cfg.max_position:
+            raise ValueError(f"position ids must lie in [0, {cfg.max_position}) (max_position_embeddings); got [{pmin}, {pmax}]")
+        if pos.numel() != len(seg):
+            raise ValueError("position ids do not match the query lengths")
+        cu = [0]
+        for q in qlens:
+            cu.append(cu[-1] + q)
+        lens_after = [c + q for c, q in zip(cache_lens, qlens)]
+        T, nseg = len(seg), len(qlens)
+        host = torch.cat([torch.tensor(seg, dtype=torch.int32), torch.tensor(slot, dtype=torch.int32), pos.reshape(-1),
+                          torch.tensor(cu, dtype=torch.int32), torch.tensor(lens_after, dtype=torch.int32)])
+        if into is None:
+            buf = host.to(dev, non_blocking=True)
+            p = ForwardPlan()
+            p.buf, p.qlens, p.max_kv = buf, qlens, 0
+            p.tok_seg, p.tok_slot, p.tok_pos = buf[:T], buf[T:2 * T], buf[2 * T:3 * T]
+            p.cu_q, p.kv_len = buf[3 * T:3 * T + nseg + 1], buf[3 * T + nseg + 1:3 * T + 2 * nseg + 1]
+            return p
+        if len(into.qlens) != nseg or sum(into.qlens) != T or max(into.qlens) != max(qlens):
+            raise ValueError("a plan can only be refreshed for the same token count, segment count and longest segment")
+        into.buf.copy_(host, non_blocking=True)     # (which segments hold the tokens may change: the kernels read it from here)
+        into.qlens = qlens
+        return into
+
     # ------------------------------------------------------------------ forward
     @ops.on_device
     def forward_inference(self, packed_query_sequence, query_lens, packed_query_position_ids,
                           packed_query_indexes=None, past_key_values: NaiveCache = None, key_values_lens=None,
                           packed_key_value_indexes=None, update_past_key_values=True, is_causal=True, mode="und",
-                          packed_vae_token_indexes=None, packed_text_indexes=None) -> BaseNavitOutputWithPast:
+                          packed_vae_token_indexes=None, packed_text_indexes=None, plan: "ForwardPlan" = None) -> BaseNavitOutputWithPast:
         cfg, w, dev = self.cfg, self.w, self.device
         nq, nkv, hd, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
         seq = packed_query_sequence
@@ -88,27 +133,13 @@ class Qwen2MoT:
             if kvl != list(cache.lens):
                 raise ValueError(f"key_values_lens {kvl} disagree with the cache ({cache.lens})")
         cache.ensure(nseg, max(c + q for c, q in zip(cache.lens, qlens)), nkv, hd, dev)
-
-        # per-token bookkeeping (host -> one small upload)
-        seg, slot = [], []
-        for s, (c, q) in enumerate(zip(cache.lens, qlens)):
-            seg += [s] * q
-            slot += list(range(c, c + q))
-        meta = torch.tensor([seg, slot], dtype=torch.int32).to(dev, non_blocking=True)
-        tok_seg, tok_slot = meta[0], meta[1]
-        # the rotary tables hold cfg.max_position rows and the kernels index them unchecked
-        pmax = int(packed_query_position_ids.max()) if packed_query_position_ids.numel() else 0
-        pmin = int(packed_query_position_ids.min()) if packed_query_position_ids.numel() else 0
-        if pmin < 0 or pmax >= cfg.max_position:
-            raise ValueError(f"position ids must lie in [0, {cfg.max_position}) (max_position_embeddings); got [{pmin}, {pmax}]")
-        tok_pos = packed_query_position_ids.to(device=dev, dtype=torch.int32)
-        cu = [0]
-        for q in qlens:
-            cu.append(cu[-1] + q)
+        if plan is None:
+            plan = self.make_plan(qlens, packed_query_position_ids, cache.lens)
+        elif plan.qlens != qlens:
+            raise ValueError("forward plan was made for other query lengths")
+        tok_seg, tok_slot, tok_pos, cu_q, kv_len = plan.tok_seg, plan.tok_slot, plan.tok_pos, plan.cu_q, plan.kv_len
         lens_after = [c + q for c, q in zip(cache.lens, qlens)]
-        cuk = torch.tensor([cu, lens_after + [0]], dtype=torch.int32).to(dev, non_blocking=True)
-        cu_q, kv_len = cuk[0], cuk[1][:nseg]
-        max_q, max_kv = max(qlens), max(lens_after)
+        max_q, max_kv = max(qlens), max(max(lens_after), plan.max_kv)
 
         gen = mode == "gen"
         expert = text_rows = vae_rows = None

@@ -556,6 +556,17 @@ def decode_step_end_argmax(tok_slot, tok_pos, kv_len, argmax_partial, ids, in_id
           "umv_decode_step_end_argmax")
 
 
+def timestep_embed(t, freqs):
+    """[n] fp32 timesteps (device) x [half] fp32 frequencies -> [n, 2*half] bf16 sinusoid (cos | sin)"""
+    lib = _lib.load()
+    _req(t, torch.float32, "t")
+    _req(freqs, torch.float32, "freqs")
+    n, half = t.numel(), freqs.numel()
+    out = torch.empty((n, 2 * half), dtype=BF16, device=t.device)
+    check(lib.umv_timestep_embed(_p(t), _p(freqs), _p(out), n, half, _stream()), "umv_timestep_embed")
+    return out
+
+
 def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img, renorm_min, rtype, dt):
     lib = _lib.load()
     _req(x_t, torch.float32, "x_t")

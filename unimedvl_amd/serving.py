@@ -153,8 +153,10 @@ class ContinuousBatcher:
         segments without queries).  Falls back to one prefill per request when the requests' image counts differ."""
         if not slots:
             return []
-        if len(slots) == 1 or len({len(r.images) for r in reqs}) != 1:
+        if len({len(r.images) for r in reqs}) != 1:
             return [self._prefill(b, r) for b, r in zip(slots, reqs)]
+        # (a single admission takes this path too: on the whole reserved cache its image span replays from a HIP graph,
+        # bagel.Bagel.forward_cache_update_vit)
         m, cache, B = self.model, self.cache, self.slots
         cap = cache.cap
         for b in slots:

@@ -19,27 +19,40 @@ class SiglipVisionModel:
     def __init__(self, cfg: UniMedVLConfig, weights: ViTWeights, device):
         self.cfg, self.w, self.device = cfg, weights, device
 
-    def __call__(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
-        return self.forward(packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen)
+    def __call__(self, packed_pixel_values=None, packed_flattened_position_ids=None, cu_seqlens=None, max_seqlen=None, plan=None):
+        return self.forward(packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen, plan=plan)
 
     @ops.on_device
-    def forward(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen):
-        cfg, w, dev = self.cfg, self.w, self.device
-        nh, hd, h_dim = cfg.vit_heads, cfg.vit_head_dim, cfg.vit_hidden
-        px = packed_pixel_values.to(device=dev, dtype=torch.float32).contiguous()
-        N = px.shape[0]
-        pos_ids = packed_flattened_position_ids.to(device=dev, dtype=torch.int64)
+    def make_plan(self, packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen, into=None):
+        """Host -> device part of a forward (pixels, position ids, segment bookkeeping) as persistent tensors; `into`
+        refreshes an existing plan in place for a same-shaped batch (the addresses a captured HIP graph reads)."""
+        dev = self.device
         cu_host = [int(v) for v in cu_seqlens.tolist()]
-        nimg = len(cu_host) - 1
-        lens = [cu_host[i + 1] - cu_host[i] for i in range(nimg)]
-        max_seqlen = int(max_seqlen)
-        cu_q = torch.tensor(cu_host, dtype=torch.int32).to(dev)
-        kv_len = torch.tensor(lens, dtype=torch.int32).to(dev)
+        lens = [cu_host[i + 1] - cu_host[i] for i in range(len(cu_host) - 1)]
+        if into is not None:
+            if into["lens"] != lens:
+                raise ValueError("a ViT plan can only be refreshed for the image sizes it was made for")
+            into["px"].copy_(packed_pixel_values.to(torch.float32), non_blocking=True)
+            into["pos_ids"].copy_(packed_flattened_position_ids.to(torch.int64), non_blocking=True)
+            return into
         seg, slot = [], []
         for i, n in enumerate(lens):
             seg += [i] * n
             slot += list(range(n))
-        meta = torch.tensor([seg, slot], dtype=torch.int32).to(dev)
+        return dict(px=packed_pixel_values.to(device=dev, dtype=torch.float32).contiguous(),
+                    pos_ids=packed_flattened_position_ids.to(device=dev, dtype=torch.int64),
+                    cu_q=torch.tensor(cu_host, dtype=torch.int32).to(dev), kv_len=torch.tensor(lens, dtype=torch.int32).to(dev),
+                    meta=torch.tensor([seg, slot], dtype=torch.int32).to(dev), lens=lens, max_seqlen=int(max_seqlen))
+
+    @ops.on_device
+    def forward(self, packed_pixel_values=None, packed_flattened_position_ids=None, cu_seqlens=None, max_seqlen=None, plan=None):
+        cfg, w, dev = self.cfg, self.w, self.device
+        nh, hd, h_dim = cfg.vit_heads, cfg.vit_head_dim, cfg.vit_hidden
+        if plan is None:
+            plan = self.make_plan(packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen)
+        px, pos_ids, cu_q, kv_len, meta, lens, max_seqlen = (plan[k] for k in ("px", "pos_ids", "cu_q", "kv_len", "meta", "lens", "max_seqlen"))
+        N = px.shape[0]
+        nimg = len(lens)
 
         xb = ops.cast_pad(px, w.k_pad)                       # autocast's fp32->bf16 cast of the pixels
         h = ops.gemm(xb, w.patch)                            # patch embedding (siglip_navit.py:190)
