@@ -6,7 +6,7 @@ TAG=${1:-pmc}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for C in FETCH_SIZE WRITE_SIZE; do
   mkdir -p gpurun_out/$TAG/$C
-  rocprofv3 --pmc $C --kernel-trace -d gpurun_out/$TAG/$C -o pmc -- python bench.py --no-cpu-baseline --no-t2i --steps 4 --warmup 1 > gpurun_out/$TAG/$C/bench.log 2>&1 || true
+  rocprofv3 --pmc $C --kernel-trace -d gpurun_out/$TAG/$C -o pmc -- python bench.py --no-cpu-baseline --no-t2i --no-fp8 --no-report --steps 4 --warmup 1 > gpurun_out/$TAG/$C/bench.log 2>&1 || true
 done
 python - <<PY
 import sqlite3, glob, json
