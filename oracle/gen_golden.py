@@ -295,6 +295,9 @@ def main():
         ver1 = inf(image=pil, text="5 6 7 8", inference_ver=1, **rec)
         torch.manual_seed(14)
         ver01 = inf.interleave_inference_for_vqa_reconstruction_ver0_1([pil, "5 6 7 8"], **rec)
+        # ver0 (inferencer.py:466-549): two input images, only the FIRST is reconstructed
+        torch.manual_seed(16)
+        ver0 = inf.interleave_inference_for_vqa_reconstruction_ver0([pil, pil, "5 6 7 8"], **rec)
         # think=True (inferencer.py:23-28,590-596,617-620): the English system prompts go through the tokenizer
         think_und = inf(image=pil, text="5 6 7 8", think=True, understanding_output=True, max_think_token_n=6)
         torch.manual_seed(15)
@@ -311,6 +314,7 @@ def main():
         edit_image=torch.from_numpy(np.asarray(edit["image"]).copy()),
         ver1_text=ver1["text"], ver1_image=torch.from_numpy(np.asarray(ver1["image"]).copy()),
         ver01_text=ver01[0], ver01_image=torch.from_numpy(np.asarray(ver01[1]).copy()),
+        ver0_text=ver0[0], ver0_image=torch.from_numpy(np.asarray(ver0[1]).copy()), ver0_len=len(ver0),
         think_und_text=think_und["text"], think_gen_text=think_gen["text"],
         think_gen_image=torch.from_numpy(np.asarray(think_gen["image"]).copy()),
         pil_image2=torch.from_numpy(arr2.copy()), chat_text=chat_text)))

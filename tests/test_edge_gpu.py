@@ -97,3 +97,23 @@ def test_generate_text_zero_and_eos(pair):
     cache2 = model.forward_cache_update_text(cache2, **gi2)
     out = model.generate_text(past_key_values=cache2, max_length=5, end_token_id=nxt, **model.prepare_start_tokens(kvl2, rope2, NEW_TOKEN_IDS))
     assert out.shape[0] == 1 and int(out[0, 0]) == BOS
+
+
+def test_out_of_range_inputs_raise_instead_of_faulting(pair):
+    """the kernels index the embedding and rotary tables unchecked; the host rejects ids / positions they do not hold
+    (position >= max_position read out of bounds, NaN logits fed an id of 0x7fffffff back into the gather)"""
+    from unimedvl_amd.decode import DecodeSession
+    from unimedvl_amd.kvcache import NaiveCache
+    model, _, cfg = pair
+    cache = NaiveCache(cfg["layers"])
+    with pytest.raises(ValueError, match="token ids"):
+        gi, _, _ = model.prepare_prompts([0], [0], ["0"], Tok([[5, cfg["vocab"] + 3]]), NEW_TOKEN_IDS)
+        model.forward_cache_update_text(cache, **gi)
+    maxpos = model.cfg.max_position
+    with pytest.raises(ValueError, match="position"):
+        gi, _, _ = model.prepare_prompts([0], [maxpos - 2], ["0"], Tok([[5, 6, 7]]), NEW_TOKEN_IDS)
+        model.forward_cache_update_text(NaiveCache(cfg["layers"]), **gi)
+    gi, kvl, rope = model.prepare_prompts([0], [0], ["0"], Tok([[5, 6]]), NEW_TOKEN_IDS)
+    cache = model.forward_cache_update_text(NaiveCache(cfg["layers"]), **gi)
+    with pytest.raises(ValueError, match="rope position"):
+        DecodeSession(model.language_model, cache, torch.tensor([BOS]), torch.tensor([maxpos - 3]), 8)

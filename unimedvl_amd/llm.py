@@ -62,6 +62,10 @@ class Qwen2MoT:
     # ------------------------------------------------------------------ embeddings / head
     @ops.on_device
     def embed_tokens(self, ids, out=None, out_rows=None):
+        if not ids.is_cuda and ids.numel():      # host-side ids (every prefill): the gather kernel indexes the table unchecked
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.w.embed.shape[0]:
+                raise ValueError(f"token ids must lie in [0, {self.w.embed.shape[0]}); got [{lo}, {hi}]")
         ids = ids.to(device=self.device, dtype=torch.int64)
         return ops.embed_gather(self.w.embed, ids, out=out, out_rows=out_rows)
 
