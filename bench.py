@@ -236,6 +236,37 @@ def _cpu_vision_legs(o, c, ntid, g, full_layers, full_vit_layers, out):
     return out
 
 
+class Comm:
+    """The few collectives of the bench (one rank per GPU, RCCL over xGMI).  backend "gloo" exists for ONE purpose: the
+    2-rank smoke test on a 1-GPU box (tests/test_bench_contract_gpu.py, UMV_BENCH_BACKEND=gloo UMV_BENCH_SHARE_GPU=1), where
+    RCCL cannot put two ranks on one device; gloo has no CUDA all-gather, so that path stages through host memory."""
+
+    def __init__(self, dist, backend, dev):
+        self.dist, self.backend, self.dev = dist, backend, dev
+        self.host = backend != "nccl"
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, value):
+        t = torch.tensor([value], dtype=torch.float64, device="cpu" if self.host else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather(self, t):
+        src = t.contiguous().cpu() if self.host else t.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, src)
+        return parts
+
+    def all_gather_into(self, out, t):
+        if not self.host:
+            self.dist.all_gather_into_tensor(out, t)
+            return
+        parts = self.all_gather(t)
+        out.copy_(torch.cat(parts, 0))
+
+
 def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128, num_timesteps=50):
     """BASELINE.json configs[2]: text-to-image, 50 diffusion steps, 256x256, batch 4 per GPU, the reference
     defaults of InterleaveInferencer.gen_image (cfg_text 4.0, cfg_img 1.5, interval (0.4,1], shift 3.0, global
@@ -291,9 +322,7 @@ def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128,
         dist.barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el = dist.max(el)
     assert len(imgs) == batch and imgs[0].shape == (hw, hw, 3) and imgs[0].dtype == torch.uint8
     ts = torch.linspace(1, 0, num_timesteps)
     ts = (3.0 * ts / (1 + 2.0 * ts))[:-1]
@@ -349,19 +378,26 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1);
         # rank 0's stdout - the one JSON line - is this process's stdout
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and not os.environ.get("UMV_BENCH_SHARE_GPU"):
             raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
         from unimedvl_amd.launch import spawn_ranks
         raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("UMV_BENCH_SHARE_GPU"):       # smoke test of the N-rank flow on a box with fewer GPUs than ranks
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
-        import torch.distributed as dist
+        import torch.distributed as tdist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("UMV_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            tdist.init_process_group("nccl", device_id=dev)
+        else:
+            tdist.init_process_group(backend)
+        dist = Comm(tdist, backend, dev)
 
     from unimedvl_amd import ops
     from unimedvl_amd.bagel import Bagel
@@ -422,7 +458,7 @@ def main():
         if dist is not None and gather == "logits":
             logits_all = torch.empty((world * B, cfg.vocab), dtype=torch.bfloat16, device=dev)
             sess.step(1)
-            dist.all_gather_into_tensor(logits_all, sess.logits)      # warm the communicator outside the timed region
+            dist.all_gather_into(logits_all, sess.logits)             # warm the communicator outside the timed region
             sess.step(warmup - 1) if warmup > 1 else None
         else:
             sess.step(warmup)
@@ -437,13 +473,13 @@ def main():
             # C1 as the north star words it: every step's [B, vocab] bf16 logits all-gathered over xGMI (scoring / parity use)
             for _ in range(steps):
                 sess.step(1)
-                dist.all_gather_into_tensor(logits_all, sess.logits)
+                dist.all_gather_into(logits_all, sess.logits)
         else:
             sess.step(steps)
         ids_local = sess.pred_ids[warmup:warmup + steps]
         if dist is not None:   # C1: gather every rank's generated ids over xGMI
-            gathered = [torch.empty_like(ids_local) for _ in range(world)]
-            dist.all_gather(gathered, ids_local.contiguous())
+            gathered = dist.all_gather(ids_local)
+            assert len(gathered) == world and gathered[rank].shape == ids_local.shape
         e1.record()
         torch.cuda.synchronize()
         if dist is not None:
@@ -451,9 +487,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            elapsed = dist.max(elapsed)
         gpu_ms = e0.elapsed_time(e1)
         sess.commit()
         toks = ids_local.cpu()
@@ -648,7 +682,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

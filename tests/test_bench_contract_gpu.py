@@ -52,3 +52,24 @@ def test_graft_entry_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("gather", ["ids", "logits"])
+def test_bench_self_launches_two_ranks(gather):
+    """`python bench.py --gpus 2` without torchrun: bench.py spawns its own ranks (unimedvl_amd.launch), they rendezvous on
+    127.0.0.1, decode, gather (C1: ids or every step's logits), barrier, take the slowest rank's time and rank 0 prints ONE line
+    with n_gpus 2 and twice one rank's tokens.  On the 1-GPU test box both ranks share cuda:0 and the collectives stage through
+    host memory over gloo (RCCL needs one device per rank); everything else is the production flow."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PYTHONDONTWRITEBYTECODE="1", UMV_BENCH_BACKEND="gloo", UMV_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "6", "--warmup", "2",
+                        "--gather", gather], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["c1_gather"] == gather
+    assert abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) <= 0.02 * d["value"]    # whole-job tokens / slowest rank's seconds
+    assert "cpu_baseline" not in d and d["t2i"]["images_per_s"] > 0
