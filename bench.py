@@ -586,7 +586,8 @@ def main():
                    "prefill_s": round(t_prefill, 3), "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": ("gemm_skinny8_kernel<1,2,4>" if lw.fp8 else "gemm_skinny_kernel<1,2>") + " (28 gate/up SwiGLU GEMMs + lm_head per step)",
+                     "kernel": ("gemm_skinny8_kernel" if lw.fp8 else "gemm_skinny_kernel") + ("<1,2,4>" if B <= 16 else "<2,4,2>" if B <= 32 else " / tiled 128x64")
+                               + " (28 gate/up SwiGLU GEMMs + lm_head per step)",
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                      "step_frac_of_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
