@@ -435,18 +435,23 @@ def main():
 
     def decode_leg(model, B=B, prompts=prompts, images=images, prompt_len=prompt_len, steps=args.steps, warmup=args.warmup,
                    gather=args.gather):
-        # ---- prefill: ViT encode + LLM prefill of the image span, then the question
-        cache = NaiveCache(cfg.layers)
-        kvl, rope = [0] * B, [0] * B
-        torch.cuda.synchronize()
-        t0 = time.time()
-        gi, kvl, rope = model.prepare_vit_images(kvl, rope, images, lambda x: x, new_token_ids)
-        cache.reserve(B, max(kvl) + prompt_len + 2 + steps + warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
-        cache = model.forward_cache_update_vit(cache, **gi)
-        gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), new_token_ids)
-        cache = model.forward_cache_update_text(cache, **gi)
-        torch.cuda.synchronize()
-        t_prefill = time.time() - t0
+        # ---- prefill: ViT encode + LLM prefill of the image span, then the question.  Run twice: the first pass pays the
+        # allocator growth and lazy module loads of a new batch shape (reported as prefill_cold_s), the second is the rate
+        def prefill():
+            cache = NaiveCache(cfg.layers)
+            kvl, rope = [0] * B, [0] * B
+            torch.cuda.synchronize()
+            t0 = time.time()
+            gi, kvl, rope = model.prepare_vit_images(kvl, rope, images, lambda x: x, new_token_ids)
+            cache.reserve(B, max(kvl) + prompt_len + 2 + steps + warmup + 8, cfg.kv_heads, cfg.head_dim, dev)
+            cache = model.forward_cache_update_vit(cache, **gi)
+            gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTokenizer(prompts), new_token_ids)
+            cache = model.forward_cache_update_text(cache, **gi)
+            torch.cuda.synchronize()
+            return cache, kvl, rope, time.time() - t0
+        cache, kvl, rope, t_cold = prefill()
+        del cache
+        cache, kvl, rope, t_prefill = prefill()
         ctx = kvl[0]
 
         # ---- decode
@@ -496,7 +501,7 @@ def main():
             mine = logits_all[rank * B:(rank + 1) * B].float().argmax(-1).cpu()
             assert torch.equal(mine, toks[-1]), "all-gathered logits do not reproduce the generated ids"
 
-        return dict(sess=sess, cache=cache, elapsed=elapsed, gpu_ms=gpu_ms, ctx=ctx, t_prefill=t_prefill)
+        return dict(sess=sess, cache=cache, elapsed=elapsed, gpu_ms=gpu_ms, ctx=ctx, t_prefill=t_prefill, t_prefill_cold=t_cold)
 
     leg = decode_leg(model)
     sess, cache, elapsed, gpu_ms, ctx, t_prefill = (leg[k] for k in ("sess", "cache", "elapsed", "gpu_ms", "ctx", "t_prefill"))
@@ -583,7 +588,9 @@ def main():
                    "c1_gather": args.gather if world > 1 else None,
                    "batch_per_gpu": B, "context_tokens": ctx, "image": f"{img_hw}x{img_hw}", "prompt_tokens": prompt_len,
                    "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
-                   "prefill_s": round(t_prefill, 3), "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},
+                   "prefill_s": round(t_prefill, 3), "prefill_cold_s": round(leg["t_prefill_cold"], 3),
+                   "prefill_images_per_s": round(world * B / t_prefill, 1),
+                   "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("gemm_skinny8_kernel" if lw.fp8 else "gemm_skinny_kernel") + ("<1,2,4>" if B <= 16 else "<2,4,2>" if B <= 32 else " / tiled 128x64")
@@ -618,7 +625,8 @@ def main():
                         f"{args.report_steps} greedy decode steps",
             "tokens_per_s": round(world * B3 * args.report_steps / l3["elapsed"], 2), "ms_per_step": round(ms3, 4),
             "decode_steps": args.report_steps, "batch_per_gpu": B3, "context_tokens": l3["ctx"],
-            "vit_prefill_s": round(l3["t_prefill"], 3), "vit_prefill_images_per_s": round(world * B3 / l3["t_prefill"], 1),
+            "vit_prefill_s": round(l3["t_prefill"], 3), "vit_prefill_cold_s": round(l3["t_prefill_cold"], 3),
+            "vit_prefill_images_per_s": round(world * B3 / l3["t_prefill"], 1),
             "end_to_end_s": round(l3["t_prefill"] + l3["elapsed"], 3),
             "end_to_end_reports_per_s": round(world * B3 / (l3["t_prefill"] + l3["elapsed"]), 3),
             "step_algorithmic_GBps": round(sb3 / (ms3 * 1e-3) / 1e9, 1),

@@ -67,6 +67,7 @@ class Bagel(BagelPrep):
         import os
         self.prefill_graph = os.environ.get("UMV_PREFILL_GRAPH", "1") not in ("0", "")   # graph replay of image spans into reserved caches
         self._vit_graphs = {}
+        self.prefill_graph_max = 8          # captured image-span graphs kept (one per cache and patch grid; ~0.1 GB of activations each)
         self.chat_cache_tokens = 0          # > 0: chat() prefills / decodes in one pooled, reserved cache of that capacity
         self._chat_cache = None
 
@@ -152,7 +153,10 @@ class Bagel(BagelPrep):
             with torch.cuda.graph(g.graph):
                 body()
             self._vit_graphs[key] = g
+            while len(self._vit_graphs) > self.prefill_graph_max:      # arbitrary image sizes: keep the most recent grids only
+                self._vit_graphs.pop(next(iter(self._vit_graphs)))
         else:
+            self._vit_graphs[key] = self._vit_graphs.pop(key)          # most recently used last
             self.vit_model.make_plan(gi["packed_vit_tokens"], gi["packed_vit_position_ids"], cu, int(gi["vit_token_seqlens"].max()), into=g.vplan)
             lm.make_plan(qlens, gi["packed_position_ids"], cache.lens, into=g.lplan)
         g.graph.replay()

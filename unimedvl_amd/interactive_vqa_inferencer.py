@@ -98,6 +98,11 @@ class VQAInferencer:
             tokenizer = load_tokenizer(model_path)
             tokenizer, new_token_ids, _ = add_special_tokens(tokenizer)
         self.model, self.tokenizer, self.new_token_ids = model, tokenizer, new_token_ids
+        # serving extra (not a reference key): every request prefills / decodes in ONE reserved cache, so the image span of a
+        # request whose patch grid was seen before replays from a HIP graph (Bagel.forward_cache_update_vit); 0 = a fresh cache
+        # per request as in the reference (bagel.py:1341)
+        if hasattr(self.model, "chat_cache_tokens"):
+            self.model.chat_cache_tokens = int(self.config.get("serving_cache_tokens", 8192))
         self.image_transform = build_transform()
         self.loaded = True
         self.show_gpu_memory()
