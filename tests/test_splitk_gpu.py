@@ -30,8 +30,8 @@ def _seq_sum(p):
     return acc
 
 
-@pytest.mark.parametrize("M", [1, 8, 16, 32, 64])
-@pytest.mark.parametrize("N,K,S", [(4608, 3584, 4), (3584, 3584, 4), (3584, 18944, 8), (320, 1000, 3), (48, 64, 2)])
+@pytest.mark.parametrize("M", [1, 8, 16, 32, 64, 65, 96, 128])       # > 64 rows: the tiled 128 x 128 kernel over k_splits K ranges
+@pytest.mark.parametrize("N,K,S", [(4608, 3584, 4), (3584, 3584, 4), (3584, 18944, 8), (320, 1000, 3), (48, 64, 2), (3584, 18944, 16)])
 def test_splitk_partials(M, N, K, S):
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
@@ -169,3 +169,49 @@ def test_decode_session_splitk_matches_default(tiny_weights, monkeypatch):
             assert torch.equal(ids0[s][sure], ids1[s][sure])
             if not torch.equal(ids0[s], ids1[s]):
                 break
+
+
+def test_decode_session_above_64_samples_matches_oracle(tiny_weights):
+    """65..128 samples per step: split-K on the tiled kernel (6, 8, 8 splits), consumers summing 6 / 8 partials, separate argmax
+    (the argmax epilogue is a <= 64-row feature); logits against the CPU oracle, teacher-forced, and graph == eager."""
+    from copy import deepcopy
+    from oracle.unimedvl_cpu import KVCache, OracleBagel
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.decode import DecodeSession
+    from unimedvl_amd.kvcache import NaiveCache
+    cfg, sd, vae_sd, _ = tiny_weights
+    model = Bagel(UniMedVLConfig.from_dict(cfg), lambda n: sd[n], device="cuda", visual_gen=False)
+    oracle = OracleBagel(cfg, sd, vae_sd)
+    B = 70
+    g = torch.Generator().manual_seed(10)
+    prompts = [[int(v) for v in torch.randint(5, 290, (2 + i % 7,), generator=g)] for i in range(B)]
+
+    class Tok:
+        def encode(self, s):
+            return prompts[int(s)]
+    bos, eos = NEW_TOKEN_IDS["bos_token_id"], NEW_TOKEN_IDS["eos_token_id"]
+    cache = NaiveCache(cfg["layers"])
+    gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], Tok(), NEW_TOKEN_IDS)
+    cache = model.forward_cache_update_text(cache, **gi)
+    oc = KVCache(cfg["layers"], B)
+    okv, orope = oracle.update_text(oc, [0] * B, [0] * B, [[bos] + p + [eos] for p in prompts])
+    assert okv == kvl and orope == rope
+    gi = model.prepare_start_tokens(kvl, rope, NEW_TOKEN_IDS)
+    runs = []
+    for use_graph in (True, False):
+        sess = DecodeSession(model.language_model, deepcopy(cache), gi["packed_start_tokens"], gi["packed_query_position_ids"], 5,
+                             use_graph=use_graph)
+        assert sess.sk == (6, 8, 8) and not sess.fused_argmax
+        lg = []
+        for _ in range(4):
+            sess.step(1)
+            lg.append(sess.logits.float().cpu())
+        runs.append((sess.in_ids[:4].cpu(), torch.stack(lg)))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    pos = torch.tensor(rope, dtype=torch.long)
+    for s in range(4):
+        h = oracle.llm_forward(oracle.embed(runs[0][0][s]), [1] * B, pos, oc, True, True, "und")
+        ref = oracle.lm_head(h).float()
+        pos = pos + 1
+        assert (runs[0][1][s] - ref).abs().max() <= 0.25, f"step {s}"

@@ -706,7 +706,8 @@ __device__ __forceinline__ void mfma16_asm(f32x4& c, const bf16x8& a, const bf16
 //     ds_read fragments of tile t, MFMAs
 // SCHED = 1: the same pipeline with the MFMAs of tile t and the ds_reads of tile t+1 interleaved by hand (see below).
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
-__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn) {
+__global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn,
+                                                                  int ksplit) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;      // 1 KiB fragment tiles per k-step
@@ -740,7 +741,12 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     const int m0 = mblk * BM;
     const int nt_blk = nblk * (BN / 16);
     const int nt_base = nt_blk + wn * TN;
-    const int nsteps = (KT + KTS - 1) / KTS;
+    // split-K (ksplit = k-tiles per split, 0 = none): blockIdx.y owns k-tiles [kt0, kt1) and stores raw fp32 partial sums
+    // (the decode GEMMs with N = 3584 / 4608 at 65..128 rows: 14-36 workgroups otherwise)
+    const int kt0 = ksplit ? (int)blockIdx.y * ksplit : 0;
+    const int kt1 = ksplit ? min(KT, kt0 + ksplit) : KT;
+    const int KTL = max(0, kt1 - kt0);
+    const int nsteps = (KTL + KTS - 1) / KTS;
 
     // ---- staging: tile f = wave*TPW + i; f < WTILES copies a W tile, otherwise gathers an x tile
     const bf16_t* src[TPW];
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             const int tl = f / KTS, kk = f % KTS;
             const int nt = nt_blk + tl;
             tvalid[i] = nt < NTT;
-            src[i] = a.wp + ((int64_t)(tvalid[i] ? nt : 0) * KT + kk) * 512 + lane * 8;
+            src[i] = a.wp + ((int64_t)(tvalid[i] ? nt : 0) * KT + kt0 + kk) * 512 + lane * 8;
         } else {
             const int fx = f - WTILES;
             const int tl = fx / KTS, kk = fx % KTS;
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             tvalid[i] = true;                       // rows past M are clamped (their outputs are masked)
             const int mm = m < a.M ? m : a.M - 1;
             const int64_t row = a.row_idx ? (int64_t)a.row_idx[mm] : (int64_t)mm;
-            src[i] = a.x + row * a.ldx + kk * 32 + g * 8;
+            src[i] = a.x + row * a.ldx + (kt0 + kk) * 32 + g * 8;
         }
     }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -775,7 +781,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         cur[i] = tvalid[i] ? src[i] : zero;
         bump[i] = !tvalid[i] ? 0 : (f < WTILES ? KTS * 512 : KTS * 32);
     }
-    const bool ragged = (KT % KTS) != 0 || (a.K & 31) != 0;     // the last k-step needs per-tile / per-lane zero fill
+    const bool ragged = (KTL % KTS) != 0 || ((a.K & 31) != 0 && kt1 == KT);     // the last k-step needs per-tile / per-lane zero fill
     auto stage = [&](int step, int buf) {
         if (ragged && step == nsteps - 1) {
 #pragma unroll
@@ -784,11 +790,11 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                 const bf16_t* p;
                 if (f < WTILES) {
                     const int kt = step * KTS + f % KTS;
-                    p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)step * (KTS * 512) : zero;
+                    p = (tvalid[i] && kt < KTL) ? src[i] + (int64_t)step * (KTS * 512) : zero;
                 } else {
                     const int kt = step * KTS + (f - WTILES) % KTS;
-                    const int k = kt * 32 + g * 8;
-                    p = (k < a.K) ? src[i] + (int64_t)step * (KTS * 32) : zero;
+                    const int k = (kt0 + kt) * 32 + g * 8;
+                    p = (kt < KTL && k < a.K) ? src[i] + (int64_t)step * (KTS * 32) : zero;
                 }
                 char* dst = smem + buf * BUF + f * 1024;
                 __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_t)dst, 16, 0, 0);
@@ -901,6 +907,10 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     }
     // epilogue with compile-time accumulator indices (a runtime-indexed acc[][] would be demoted to scratch)
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
+    if (ksplit) {   // partial sums: fp32, no bias / activation / residual (umv_qkv_post / umv_residual_rmsnorm_bf16 finish the row)
+        e.out = reinterpret_cast<float*>(a.out) + (int64_t)blockIdx.y * a.split_stride;
+        e.flags = UMV_EPI_OUT_F32;
+    }
     const bool swiglu = (a.epilogue & UMV_EPI_SWIGLU) != 0;
     static_for<0, TM>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -947,8 +957,10 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
         attr_set = true;
     }
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT,
-                       NTT, mblocks, nblocks, raster_gn());
+    const int splits = a.k_splits > 1 ? a.k_splits : 1;
+    const int ksplit = splits > 1 ? ((KT + splits - 1) / splits + KTS - 1) / KTS * KTS : 0;    // whole k-steps per split
+    hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>), dim3(mblocks * nblocks, splits), dim3(WN * WM * 64), lds, s, a,
+                       KT, NTT, mblocks, nblocks, raster_gn(), ksplit);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -997,8 +1009,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm: SWIGLU needs N %% 32 == 0");
     UMV_CHECK(!a.norm_w || (a.M <= 16 && a.K <= SK_WAVES * SK_XMAX * 32), UMV_ERR_UNSUPPORTED,
               "gemm: fused RMSNorm needs M <= 16 and K <= %d (got M=%d K=%d)", SK_WAVES * SK_XMAX * 32, a.M, a.K);
-    UMV_CHECK(a.k_splits <= 1 || (a.M <= 64 && !a.norm_w && !(a.epilogue & UMV_EPI_SWIGLU) && a.tile_rows % 16 == 0 && a.split_stride > 0),
-              UMV_ERR_UNSUPPORTED, "gemm: split-K (k_splits=%d) is a decode mode: M <= 64, 16-row image, no SwiGLU / fused norm, "
+    UMV_CHECK(a.k_splits <= 1 || (a.M <= 128 && !a.norm_w && !(a.epilogue & UMV_EPI_SWIGLU) && a.tile_rows % 16 == 0 && a.split_stride > 0),
+              UMV_ERR_UNSUPPORTED, "gemm: split-K (k_splits=%d) is a decode mode: M <= 128, 16-row image, no SwiGLU / fused norm, "
               "split_stride > 0", a.k_splits);
     UMV_CHECK(a.k_splits <= 64, UMV_ERR_ARG, "gemm: k_splits %d > 64", a.k_splits);
     UMV_CHECK(!a.argmax_partial || (a.M <= 64 && a.k_splits <= 1 && !a.row_idx && !a.norm_w && (a.tile_rows == 0 || a.tile_rows == 16) &&
@@ -1015,6 +1027,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     const int NTT = (a.N + TH - 1) / TH;
     static int skinny_max = -1;   // tuning only: UMV_GEMM_SKINNY_MAX=<M> (rows up to which the weight-streaming kernel is used)
     if (skinny_max < 0) { const char* e = getenv("UMV_GEMM_SKINNY_MAX"); skinny_max = e ? atoi(e) : 64; }
+    if (a.k_splits > 1 && a.M > 64)    // 65..128 rows: the 128 x 128 tile (two workgroups per CU) over k_splits K ranges, fp32 partials
+        return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);
     if (a.k_splits > 1) {
         // split-K decode GEMM: 4 n-tiles per workgroup share every x fragment (x re-reads from L2 drop 4x against the
         // one-tile workgroups), the K range is cut k_splits ways to keep >= 256 workgroups, partial sums go to fp32

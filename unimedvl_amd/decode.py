@@ -96,12 +96,14 @@ class DecodeSession:
         if sk == "auto":
             # (B <= 8 bf16: 3,4,4 3.151 ms vs 3,1,4 3.161 - a wash, so one setting for every batch and weight type; it also
             # makes the exact-partition copy of the o_proj weights unnecessary)
-            sk = "0" if B > 64 else "3,4,4"
+            # 65..128 rows: the same scheme on the 128 x 128 MFMA tile (umv_gemm_bf16 routes k_splits > 1 there above 64 rows):
+            # without it down_proj is 14 workgroups of 256 x 256 (151 us); bf16 weights only (the e4m3 image is an M <= 64 layout)
+            sk = "3,4,4" if B <= 64 else ("6,8,8" if B <= 128 and not getattr(w, "fp8", False) else "0")
         self.sk = (1, 1, 1) if sk in ("0", "") else tuple(max(1, int(v)) for v in sk.split(","))
         if len(self.sk) != 3 or any(v > 64 for v in self.sk):
             raise ValueError(f"UMV_DECODE_SPLITK={sk!r}: expected 'q,o,d' with 1 <= splits <= 64")
-        if self.sk != (1, 1, 1) and B > 64:
-            raise ValueError("split-K decode mode serves at most 64 samples per step")
+        if self.sk != (1, 1, 1) and B > 128:
+            raise ValueError("split-K decode mode serves at most 128 samples per step")
         sq, so, sd = self.sk
         self.p_qkv = torch.empty((sq, B, (nq + 2 * nkv) * hd), dtype=torch.float32, device=dev) if sq > 1 else None
         self.p_h = torch.empty((max(so, sd), B, H), dtype=torch.float32, device=dev) if max(so, sd) > 1 else None
