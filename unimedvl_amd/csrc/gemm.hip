@@ -1027,7 +1027,9 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     const int NTT = (a.N + TH - 1) / TH;
     static int skinny_max = -1;   // tuning only: UMV_GEMM_SKINNY_MAX=<M> (rows up to which the weight-streaming kernel is used)
     if (skinny_max < 0) { const char* e = getenv("UMV_GEMM_SKINNY_MAX"); skinny_max = e ? atoi(e) : 64; }
-    if (a.k_splits > 1 && a.M > 64)    // 65..128 rows: the 128 x 128 tile (two workgroups per CU) over k_splits K ranges, fp32 partials
+    static int sk_tiled_min = -1;   // tuning only: UMV_SPLITK_TILED_MIN=<rows from which split-K runs on the tiled kernel>
+    if (sk_tiled_min < 0) { const char* e = getenv("UMV_SPLITK_TILED_MIN"); sk_tiled_min = e ? atoi(e) : 65; }
+    if (a.k_splits > 1 && (a.M > 64 || a.M >= sk_tiled_min) && TH == 16)    // 65..128 rows: the 128 x 128 tile (two workgroups per CU) over k_splits K ranges, fp32 partials
         return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);
     if (a.k_splits > 1) {
         // split-K decode GEMM: 4 n-tiles per workgroup share every x fragment (x re-reads from L2 drop 4x against the
