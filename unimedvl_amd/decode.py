@@ -67,7 +67,11 @@ class DecodeSession:
         # split the key range so that every wavefront walks ~2 blocks of 32 keys (latency bound otherwise)
         if nsplit is None and os.environ.get("UMV_DECODE_NSPLIT"):
             nsplit = int(os.environ["UMV_DECODE_NSPLIT"])   # tuning only
-        self.nsplit = nsplit if nsplit is not None else max(1, min(32, (max_kv + 63) // 64))
+        # ... but no more than ~1024 waves in all: with many samples the partial (O, m, l) traffic and the combine grow with the
+        # split count (B = 32, context 1156: 4.45 ms per step at 8 splits, 4.53 at 19; B = 8 is unchanged by the cap)
+        if nsplit is None:
+            nsplit = max(1, min(32, (max_kv + 63) // 64, max(1, 1024 // (B * nkv))))
+        self.nsplit = nsplit
         self.ws = ops.attn_workspace(B, nq, hd, 1, self.nsplit, dev) if self.nsplit > 1 else None
         self.max_kv = max_kv
         # static activations
