@@ -192,32 +192,44 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
                 rescale = rescale || __any(alpha[u] != 1.0f);
             }
             // ---- O^T += V^T P^T : one V^T fragment from LDS feeds the TQ tiles
-            const bool partial = kb + 32 > Lk;
-            const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
-            asm volatile("s_nop 4" ::: "memory");   // the probabilities were packed by VALU code; the MFMAs below are asm
+            // Straight-line code: the rescale and the tail mask are hoisted out of the dt loop as wave-uniform branches, so the
+            // DT fragment reads are all in flight before the first MFMA (with the branches inside the loop every fragment was a
+            // ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs basic block of its own: 8 exposed LDS latencies per block).
+            // The accumulators stay in VGPRs ("+v"): as MFMA C/D operands of the builtin the compiler parks all 64 of them in
+            // AGPRs and moves them out and back around every rescale.  The asm is opaque to the hazard recogniser, and VALU write
+            // -> MFMA read is NOT interlocked: each VALU-written MFMA operand (rescaled accumulators, masked fragments, packed
+            // probabilities) is pinned ("+v") AFTER its last write and BEFORE one s_nop 4, which precedes the first MFMA.
+            // The MFMA results are next read by VALU code a whole block later, or after the s_nops behind the loop.
+            bf16x8 vf[DT];
 #pragma unroll
-            for (int u = 0; u < TQ; ++u) asm volatile("" : "+v"(pf[u]));
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
+            if (rescale) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
-                if (partial) {
-                    v = attn_mask_keys(v, nvalid);
-                    asm volatile("s_nop 4" : "+v"(v));    // VALU write -> (asm) MFMA read of the masked fragment
-                }
+                for (int u = 0; u < TQ; ++u)
 #pragma unroll
-                for (int u = 0; u < TQ; ++u) {
-                    // the accumulators stay in VGPRs ("+v"): as MFMA C/D operands of the builtin the compiler parks all 64 of
-                    // them in AGPRs and moves them out and back around every rescale (64 v_accvgpr_write per block)
-                    // (the asm is opaque to the hazard recogniser, and VALU write -> MFMA read is NOT interlocked: without the
-                    // s_nops after the mask / rescale / probability packing the MFMA read stale operands and produced NaNs.
-                    // The MFMA results are next read by VALU code a whole block later, or after the s_nops behind the loop.)
-                    if (rescale) {
+                    for (int dt = 0; dt < DT; ++dt) {
                         o[u][dt].x *= alpha[u]; o[u][dt].y *= alpha[u]; o[u][dt].z *= alpha[u]; o[u][dt].w *= alpha[u];
-                        asm volatile("s_nop 4" : "+v"(o[u][dt]));
                     }
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(o[u][dt]) : "v"(v), "v"(pf[u]));
-                }
             }
+            if (kb + 32 > Lk) {     // the last, partial block of the segment: zero the keys beyond Lk
+                const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) vf[dt] = attn_mask_keys(vf[dt], nvalid);
+            }
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) {
+                asm volatile("" : "+v"(pf[u]));
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) asm volatile("" : "+v"(o[u][dt]));
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) asm volatile("" : "+v"(vf[dt]));
+            asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < TQ; ++u)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(o[u][dt]) : "v"(vf[dt]), "v"(pf[u]));
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read wait states for the asm MFMAs above

@@ -16,15 +16,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ----------------------------------------------------------------------------- epilogue math
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3))), with tanh(u) = 1 - 2/(2^(2u*log2 e) + 1)
-    // on v_exp_f32 / v_rcp_f32 (abs error ~1e-7, far below the bf16 rounding that follows; libm's tanhf is ~40 VALU ops)
-    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-    const float kKappa = 0.044715f;
-    float x3 = x * x * x;
-    float inner = kBeta * (x + kKappa * x3);
-    float e = __builtin_amdgcn_exp2f(fminf(inner * 2.8853900817779268f, 126.0f));   // 2^(2u log2 e), clamped: no inf/inf
-    float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return 0.5f * x * (1.0f + th);
+    // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3).  With tanh(u) = 1 - 2/(e^(2u)+1) this is
+    // x / (1 + e^(-2u)) = x * rcp(1 + 2^(x*(c0 + c1*x^2))): 7 VALU ops, two of them v_exp_f32 / v_rcp_f32 (libm's tanhf is ~40;
+    // the textbook form 15).  Abs error ~1e-7, far below the bf16 rounding that follows.  The exponent is clamped so that
+    // 2^(..) stays finite: x -> -inf gives -0 like the reference, never inf * 0.
+    const float c0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f;   // -2 log2(e) sqrt(2/pi)
+    const float c1 = c0 * 0.044715f;
+    const float p = __builtin_fmaf(c1, x * x, c0);
+    const float e = __builtin_amdgcn_exp2f(fminf(x * p, 126.0f));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 // x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (relative error ~2e-7 before the bf16 rounding)
 __device__ __forceinline__ float silu_f(float x) {
@@ -77,14 +77,31 @@ __device__ __forceinline__ void epi_argmax_tile(uint64_t* __restrict__ partial, 
     if (valid && (lane >> 4) == 0) partial[(int64_t)m * ld_partial + tile] = key;
 }
 
-// Finish 4 consecutive n (n0..n0+3) of row `orow` from fp32 accumulators.  `final` (optional) receives the stored values.
+// The bias of columns n0..n0+3 (zero beyond N): one 8-byte load when the four columns exist and the address is 8-byte aligned.
+__device__ __forceinline__ void epi_bias4(const EpiCtx& e, int n0, float* b) {
+    const bf16_t* bp = e.bias + n0;
+    if (n0 + 3 < e.N && ((reinterpret_cast<uintptr_t>(bp) & 7) == 0)) {
+        const u32x2 pk = *reinterpret_cast<const u32x2*>(bp);
+        b[0] = __uint_as_float(pk.x << 16); b[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+        b[2] = __uint_as_float(pk.y << 16); b[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (n0 + j < e.N) ? bf2f(bp[j]) : 0.f;
+    }
+}
+
+// Finish 4 consecutive n (n0..n0+3) of row `orow` from fp32 accumulators; `bias4` = epi_bias4's values when the caller has
+// them already (the tiled kernel loads them once per column group, not once per row).  `final` (optional) receives the
+// stored values.
 __device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0, float v0, float v1, float v2, float v3,
-                                           float* final = nullptr) {
+                                           float* final = nullptr, const float* bias4 = nullptr) {
     float v[4] = {v0, v1, v2, v3};
     if (e.flags & UMV_EPI_BIAS) {
+        float bl[4];
+        if (!bias4) epi_bias4(e, n0, bl);
+        const float* b = bias4 ? bias4 : bl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < e.N) v[j] += bf2f(e.bias[n0 + j]);
+        for (int j = 0; j < 4; ++j) v[j] += b[j];      // columns beyond N carry a zero bias and are never stored
     }
     if (e.flags & UMV_EPI_OUT_F32) {
         float* o = reinterpret_cast<float*>(e.out) + orow * e.ldo + n0;
@@ -105,16 +122,22 @@ __device__ __forceinline__ void epi_store4(const EpiCtx& e, int64_t orow, int n0
     }
     if (e.flags & UMV_EPI_RESIDUAL) {
         const bf16_t* rr = e.residual + orow * e.ldr + n0;
+        if (n0 + 3 < e.N && ((reinterpret_cast<uintptr_t>(rr) & 7) == 0)) {   // one 8-byte load
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(rr);
+            v[0] = rbf(v[0] + __uint_as_float(pk.x << 16)); v[1] = rbf(v[1] + __uint_as_float(pk.x & 0xFFFF0000u));
+            v[2] = rbf(v[2] + __uint_as_float(pk.y << 16)); v[3] = rbf(v[3] + __uint_as_float(pk.y & 0xFFFF0000u));
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n0 + j < e.N) v[j] = rbf(v[j] + bf2f(rr[j]));
+            for (int j = 0; j < 4; ++j)
+                if (n0 + j < e.N) v[j] = rbf(v[j] + bf2f(rr[j]));
+        }
     }
     if (final) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) final[j] = v[j];     // already bf16-exact (every branch above ends in rbf)
     }
     bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + n0;
-    if (n0 + 3 < e.N && (((e.ldo | n0) & 3) == 0)) {   // 8-byte aligned: one packed store
+    if (n0 + 3 < e.N && ((reinterpret_cast<uintptr_t>(o) & 7) == 0)) {   // 8-byte aligned: one packed store
         u32x2 pk;
         pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
         pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
@@ -144,6 +167,157 @@ __device__ __forceinline__ void epi_swiglu4(const EpiCtx& e, int64_t orow, int c
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (c0 + j < I) o[j] = f2bf(v[j]);
+    }
+}
+
+// ----------------------------------------------------------------------------- wave-tile epilogue through LDS
+// The MFMA accumulator layout gives a lane 4 consecutive columns of one row: stored directly, a wave's store instruction
+// covers 16 rows x 32 bytes - 16 partial cache lines, and TN*TM such instructions per wave (the store tail of a 256 x 256
+// tile measured 15-31 us of an 87-118 us ViT GEMM, 14 % of the 8208 x 18944 x 3584 prefill GEMM).  Here every wave
+// transposes its own (TM*16) x (TN*16) tile through its own LDS region (the staging buffers are free after the main loop;
+// no cross-wave traffic, so no barrier beyond the caller's "everyone left the main loop"):
+//   phase 1  accumulator layout: (* scales) + bias -> bf16 -> activation -> bf16 (or SwiGLU of the gate / up tile pair),
+//            ds_write_b64 at [row][16-byte chunk ^ (row & (CH-1))] (XOR swizzle: at most 2-way bank conflicts, no padding);
+//   phase 2  row layout: ds_read_b128 (conflict free), + residual with a 16-byte load, one 16-byte store per lane - a wave
+//            instruction covers 64/CH whole rows of the wave tile (256 contiguous bytes each at TN = 8).
+// Arithmetic and rounding points are those of epi_store4 / epi_swiglu4: results are bit-identical to the direct path.
+// sw (per column) / sx (per row), optional: dequantisation scales of the fp8 kernels, applied to the raw accumulator.
+template <int TN, int TM>
+__device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[TN][TM], char* wreg, int lane, int m_wave0, int M,
+                                                  const int32_t* __restrict__ row_idx, int nt_base, int NTT,
+                                                  const bf16_t* bias_tile = nullptr,   // LDS copy of bias[nt_base*16 ..], zero past N
+                                                  const float* __restrict__ sw = nullptr, const float* __restrict__ sx = nullptr) {
+    const int r = lane & 15, g = lane >> 4;
+    const bool swiglu = (e.flags & UMV_EPI_SWIGLU) != 0;
+    float sxr[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m_wave0 + j * 16 + r;
+        sxr[j] = sx ? sx[m < M ? m : M - 1] : 1.f;
+    }
+    auto finish = [&](auto CHC, int col_base, int n_out) {
+        constexpr int CH = decltype(CHC)::value;           // 16-byte chunks per row of the wave tile
+        constexpr int ROWB = CH * 16, RPI = 64 / CH, NI = TM * 16 / RPI;
+        const int row_l = lane / CH, chunk = lane % CH;
+        const int col0 = col_base + chunk * 8;
+        if (col0 >= n_out) return;
+        const bool full = col0 + 7 < n_out;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * RPI + row_l;
+            const int m = m_wave0 + row;
+            if (m >= M) continue;
+            u32x4 v = *reinterpret_cast<const u32x4*>(wreg + row * ROWB + ((chunk ^ (row & (CH - 1))) << 4));
+            const int64_t orow = row_idx ? (int64_t)row_idx[m] : (int64_t)m;
+            bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + col0;
+            if (e.flags & UMV_EPI_RESIDUAL) {
+                const bf16_t* rr = e.residual + orow * e.ldr + col0;
+                uint32_t rw[4];
+                if (full && ((reinterpret_cast<uintptr_t>(rr) & 15) == 0)) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(rr);
+                    rw[0] = rv.x; rw[1] = rv.y; rw[2] = rv.z; rw[3] = rv.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t lo = (col0 + 2 * q < n_out) ? rr[2 * q] : 0, hi = (col0 + 2 * q + 1 < n_out) ? rr[2 * q + 1] : 0;
+                        rw[q] = lo | (hi << 16);
+                    }
+                }
+                uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    vw[q] = pack2bf(__uint_as_float(vw[q] << 16) + __uint_as_float(rw[q] << 16),
+                                    __uint_as_float(vw[q] & 0xFFFF0000u) + __uint_as_float(rw[q] & 0xFFFF0000u));
+                v.x = vw[0]; v.y = vw[1]; v.z = vw[2]; v.w = vw[3];
+            }
+            if (full && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                *reinterpret_cast<u32x4*>(o) = v;
+            } else {
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (col0 + q < n_out) o[q] = (bf16_t)(vw[q >> 1] >> ((q & 1) * 16));
+            }
+        }
+    };
+    if (swiglu) {
+        constexpr int CH = TN;                    // TN/2 output tiles of 16 columns = 32 bytes each
+        static_for<0, TN / 2>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            static_for<0, TM>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int row = j * 16 + r;
+                float v[4];
+                const float gg[4] = {acc[2 * p][j].x, acc[2 * p][j].y, acc[2 * p][j].z, acc[2 * p][j].w};
+                const float uu[4] = {acc[2 * p + 1][j].x, acc[2 * p + 1][j].y, acc[2 * p + 1][j].z, acc[2 * p + 1][j].w};
+                if (sw) {
+                    const int ng = (nt_base + 2 * p) * 16 + g * 4, nu = ng + 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a_ = rbf(gg[q] * sw[min(ng + q, e.N - 1)] * sxr[j]), b_ = rbf(uu[q] * sw[min(nu + q, e.N - 1)] * sxr[j]);
+                        v[q] = rbf(rbf(silu_f(a_)) * b_);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = rbf(rbf(silu_f(rbf(gg[q]))) * rbf(uu[q]));
+                }
+                u32x2 pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                const int chunk = 2 * p + (g >> 1);
+                *reinterpret_cast<u32x2*>(wreg + row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4) + (g & 1) * 8) = pk;
+            });
+        });
+        finish(std::integral_constant<int, CH>{}, (nt_base >> 1) * 16, e.N / 2);
+    } else {
+        constexpr int CH = 2 * TN;
+        static_for<0, TN>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const int n0 = (nt_base + t) * 16 + g * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (e.flags & UMV_EPI_BIAS) {
+                if (bias_tile) {
+                    const u32x2 pk = *reinterpret_cast<const u32x2*>(bias_tile + t * 16 + g * 4);
+                    b4[0] = __uint_as_float(pk.x << 16); b4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+                    b4[2] = __uint_as_float(pk.y << 16); b4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+                } else if (n0 < e.N) {
+                    epi_bias4(e, n0, b4);
+                }
+            }
+            if (sw) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s4[q] = sw[min(n0 + q, e.N - 1)];
+            }
+            static_for<0, TM>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int row = j * 16 + r;
+                float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
+                if (sw) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] * s4[q] * sxr[j];
+                }
+                if (e.flags & UMV_EPI_BIAS) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += b4[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = rbf(v[q]);
+                if (e.flags & UMV_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = rbf(gelu_tanh_f(v[q]));
+                }
+                if (e.flags & UMV_EPI_SILU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = rbf(silu_f(v[q]));
+                }
+                u32x2 pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                const int chunk = 2 * t + (g >> 1);
+                *reinterpret_cast<u32x2*>(wreg + row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4) + (g & 1) * 8) = pk;
+            });
+        });
+        finish(std::integral_constant<int, CH>{}, nt_base * 16, e.N);
     }
 }
 
