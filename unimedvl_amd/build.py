@@ -18,6 +18,9 @@ LIB = os.path.join(LIBDIR, "libunimedvl_hip.so")
 SOURCES = ["elementwise.hip", "gemm.hip", "gemm_decode.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "attention_decode.hip", "vision.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+# per-file additions.  attention_prefill: MFMA destinations stay in VGPRs (the compiler's default parks the 64 O accumulators in
+# AGPRs and moves them out and back around every rescale)
+FILE_FLAGS = {"attention_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stamp():
@@ -27,6 +30,7 @@ def _stamp():
         if os.path.isfile(p):
             h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -44,7 +48,7 @@ def build(force=False, verbose=True):
         if not os.path.exists(sp):
             continue
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -4,7 +4,7 @@
 // attention.hip's attn_kernel lets every wave stream its own K / V^T fragments from L2: with 64-128 q-tiles per
 // (segment, kv head) that is 64-128x the K/V bytes through L2->L1 (ViT: 2.4 GB per layer = 12 TB/s, the measured ceiling
 // of that path).  Here the 4 waves of a workgroup take TQ q-tiles each (4*TQ tiles of the same segment / kv head) and
-// share every 64-key stage through LDS:
+// share every 32- or 64-key stage through LDS:
 //   * LDS-DMA gathers the K and V^T fragments straight into MFMA fragment order (every lane supplies its own source
 //     address, the destination is lane-linear, so the consumers' ds_read_b128 are conflict free), double buffered, one
 //     barrier per stage;
@@ -15,16 +15,19 @@
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 __device__ __attribute__((aligned(16))) const uint32_t g_attn_zero_page[4] = {0, 0, 0, 0};
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 
-// 32-key blocks per LDS stage.  hd 128: one (2 x 16 KiB per workgroup, so three workgroups share a CU - the kernel's 156
-// VGPRs allow three waves per SIMD - and hide each other's softmax latency chains: 354 -> 341 us per LLM prefill layer);
-// hd 72: two (fewer barriers win there: 120 vs 124 us per ViT layer).  Same block order either way: bit-identical.
-// Only with TQ = 2, i.e. on large grids: a small grid (the 34-token text prefill: 128 workgroups, TQ = 1) has no
-// co-resident workgroup to hide the one-stage prefetch distance behind, and 32-key stages cost it 47 -> 126 us per layer.
-constexpr int ATTN_PREFILL_NB(int hd, int tq) { return (hd > 96 && tq == 2) ? 1 : 2; }
+// 32-key blocks per LDS stage and the occupancy asked of the register allocator.  The kernel is latency bound (every wave runs
+// K reads -> QK^T -> softmax chain -> V reads -> PV in series; MFMA and VALU pipes are each < 35 % busy), so resident waves are
+// what buys throughput: TQ = 2 uses one block per stage (hd 128: 2 x 16 KiB per workgroup, 162 VGPRs = 3 waves per SIMD;
+// hd 72: 2 x 11 KiB, held to 128 VGPRs = 4 waves per SIMD: 102 -> 93 us per ViT layer).  TQ = 1, i.e. small grids (the
+// 34-token text prefill: 128 workgroups), has no co-resident workgroup to hide the one-stage prefetch distance behind and
+// keeps two blocks per stage (32-key stages cost it 47 -> 126 us per layer).  Same block order either way: bit-identical.
+constexpr int ATTN_PREFILL_NB(int hd, int tq) { return (tq == 2) ? 1 : 2; }
+constexpr int ATTN_PREFILL_WAVES(int hd, int tq) { return (hd <= 96 && tq == 2) ? 4 : 1; }   // minimum waves per SIMD asked of the register allocator
 
 __device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // keep the first nvalid (0..8) elements
     bf16x8 o;
@@ -34,7 +37,7 @@ __device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // ke
 }
 
 template <int HD, int TQ>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, float scale_log2e) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e) {
     constexpr int KS = (HD + 31) / 32;
     constexpr int DT = (HD + 15) / 16;
     constexpr int FK = 2 * KS, FB = FK + DT;   // fragments (1 KiB each) per 32-key block: K then V^T
@@ -134,8 +137,6 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
             f32x4 st[TQ][2];
 #pragma unroll
             for (int u = 0; u < TQ; ++u) st[u][0] = st[u][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // (the score accumulators stay with the builtin: pinning them in VGPRs too costs more in hand-placed wait states
-            // than the 16 v_accvgpr_read per block it removes - 395 vs 369 us per LLM prefill layer)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -193,16 +194,17 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
             }
             // ---- O^T += V^T P^T : one V^T fragment from LDS feeds the TQ tiles
             // Straight-line code: the rescale and the tail mask are hoisted out of the dt loop as wave-uniform branches, so the
-            // DT fragment reads are all in flight before the first MFMA (with the branches inside the loop every fragment was a
+            // fragment reads are in flight before the first MFMA (with the branches inside the loop every fragment was a
             // ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs basic block of its own: 8 exposed LDS latencies per block).
-            // The accumulators stay in VGPRs ("+v"): as MFMA C/D operands of the builtin the compiler parks all 64 of them in
-            // AGPRs and moves them out and back around every rescale.  The asm is opaque to the hazard recogniser, and VALU write
-            // -> MFMA read is NOT interlocked: each VALU-written MFMA operand (rescaled accumulators, masked fragments, packed
-            // probabilities) is pinned ("+v") AFTER its last write and BEFORE one s_nop 4, which precedes the first MFMA.
-            // The MFMA results are next read by VALU code a whole block later, or after the s_nops behind the loop.
-            bf16x8 vf[DT];
+            // Every MFMA is the builtin; the file is compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py), which keeps all
+            // MFMA destinations in VGPRs: by default the compiler parks the 64 O accumulators in AGPRs and moves them out and
+            // back around every rescale (PMC then: 15 VALU instructions per MFMA).  Hazards and waits are the compiler's.
+            constexpr int H0 = (DT + 1) / 2;      // V^T fragments in two halves: half the registers, the second half's reads fly
+            const bool tail = kb + 32 > Lk;       // behind the first half's MFMAs.  tail: the last, partial block of the segment
+            const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
+            bf16x8 vfa[H0];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vf[dt] = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
+            for (int dt = 0; dt < H0; ++dt) vfa[dt] = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
             if (rescale) {
 #pragma unroll
                 for (int u = 0; u < TQ; ++u)
@@ -211,32 +213,28 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
                         o[u][dt].x *= alpha[u]; o[u][dt].y *= alpha[u]; o[u][dt].z *= alpha[u]; o[u][dt].w *= alpha[u];
                     }
             }
-            if (kb + 32 > Lk) {     // the last, partial block of the segment: zero the keys beyond Lk
-                const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
+            if (tail) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) vf[dt] = attn_mask_keys(vf[dt], nvalid);
+                for (int dt = 0; dt < H0; ++dt) vfa[dt] = attn_mask_keys(vfa[dt], nvalid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 vfb[DT - H0];
+#pragma unroll
+            for (int dt = H0; dt < DT; ++dt) vfb[dt - H0] = *reinterpret_cast<const bf16x8*>(fb + (FK + dt) * 1024);
+#pragma unroll
+            for (int dt = 0; dt < H0; ++dt)
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) o[u][dt] = mfma16(vfa[dt], pf[u], o[u][dt]);
+            if (tail) {
+#pragma unroll
+                for (int dt = H0; dt < DT; ++dt) vfb[dt - H0] = attn_mask_keys(vfb[dt - H0], nvalid);
             }
 #pragma unroll
-            for (int u = 0; u < TQ; ++u) {
-                asm volatile("" : "+v"(pf[u]));
+            for (int dt = H0; dt < DT; ++dt)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) asm volatile("" : "+v"(o[u][dt]));
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) asm volatile("" : "+v"(vf[dt]));
-            asm volatile("s_nop 4" ::: "memory");
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int u = 0; u < TQ; ++u)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(o[u][dt]) : "v"(vf[dt]), "v"(pf[u]));
+                for (int u = 0; u < TQ; ++u) o[u][dt] = mfma16(vfb[dt - H0], pf[u], o[u][dt]);
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read wait states for the asm MFMAs above
-#pragma unroll
-    for (int u = 0; u < TQ; ++u)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) asm volatile("" : "+v"(o[u][dt]));
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         if (!rvalid[u]) continue;
@@ -254,6 +252,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(umv_attn_args a, floa
         }
     }
 }
+
 
 // UMV_ATTN_SHARED=0 falls back to the per-wave streaming kernel; UMV_ATTN_TQ=1|2 picks the q-tiles per wave (A/B only)
 bool umv_attn_prefill_enabled() {
