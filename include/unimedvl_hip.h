@@ -252,6 +252,12 @@ typedef struct {
     int max_kv; /* upper bound of kv_len (grid sizing for nsplit) */
     int nsplit;
     void* workspace;
+    /* Optional in-place operands (0 = the defaults above).  q_row_stride: elements between consecutive query rows (default
+     * nq*hd; the q columns of a fused [T, (nq+2nkv)*hd] QKV buffer are read where the GEMM left them).  k_key_stride > 0: K is
+     * NOT a slab but a packed [T, ...] buffer like q - key p of segment s is row cu_q[s] + p, k_slab points at its first K
+     * column, k_head_stride is the head pitch inside a row, k_seg_stride is ignored (self-attention without a cache: the
+     * SigLIP tower, siglip_navit.py:232-241).  V^T always comes from vt_slab. */
+    int64_t q_row_stride, k_key_stride;
 } umv_attn_args;
 size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit);
 int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);

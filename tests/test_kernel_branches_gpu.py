@@ -269,6 +269,59 @@ def test_attn_prefill_tq1_still_covered(ops):
     _attn_run(ops, 16, 16, 72, [1024], [1024], False, 91, want_tq=1)
 
 
+@pytest.mark.parametrize("lens", [[1024] * 8, [1024, 512, 768, 1000, 256, 77], [1024], [77, 40], [5, 3]])
+def test_attn_in_place_qk_equals_slab_form(ops, lens):
+    """The cache-less self-attention form of the SigLIP tower (siglip_navit.py:222-241): q and K are read where the QKV GEMM wrote
+    them - column slices of the fused [T, 3*1152] buffer (q_row_stride / k_key_stride) - and only V goes through qkv_post
+    (V-only split into V^T).  Same bits as the slab form (q copy + K slab), on the LDS-shared kernels (TQ = 2, TQ = 1) and on
+    the per-wave kernel (tiny segments), ragged lengths included."""
+    nh, hd = 16, 72
+    T, nseg = sum(lens), len(lens)
+    qkv = rnd((T, 3 * nh * hd), 500 + T)
+    cap = (max(lens) + 31) // 32 * 32
+    seg = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(lens)]).cuda()
+    slot = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).cuda()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32).cuda()
+    kvl = torch.tensor(lens, dtype=torch.int32).cuda()
+    # slab form
+    slab = ops.KVSlab(nseg, nh, cap, hd, "cuda")
+    q = torch.zeros((T, nh, hd), dtype=BF16, device="cuda")
+    ops.qkv_post(qkv, q, slab, seg, slot, None, nh, nh, hd)
+    ref = torch.zeros((T, nh * hd), dtype=BF16, device="cuda")
+    ops.attention(q, ref, slab, cu, kvl, nh, nh, hd, False, max(lens), max(lens))
+    # in-place form
+    vslab = ops.KVSlab(nseg, nh, cap, hd, "cuda", keys=False)
+    assert vslab.k is None
+    ops.qkv_post(qkv, None, vslab, seg, slot, None, nh, nh, hd)
+    assert torch.equal(vslab.vt, slab.vt)
+    out = torch.zeros_like(ref)
+    ops.attention(qkv[:, :nh * hd], out, vslab, cu, kvl, nh, nh, hd, False, max(lens), max(lens), k_packed=qkv[:, nh * hd:2 * nh * hd])
+    assert torch.isfinite(out.float()).all() and out.float().abs().max() > 0
+    assert torch.equal(out, ref)
+    # and against the fp32 flash model
+    ks = [qkv[int(cu[i]):int(cu[i + 1]), nh * hd:2 * nh * hd].reshape(-1, nh, hd) for i in range(nseg)]
+    vs = [qkv[int(cu[i]):int(cu[i + 1]), 2 * nh * hd:].reshape(-1, nh, hd) for i in range(nseg)]
+    model = _attn_ref(qkv[:, :nh * hd].reshape(T, nh, hd).contiguous(), ks, vs, lens, False)
+    assert (out.view(T, nh, hd).float() - model.float()).abs().max().item() < 0.03
+
+
+def test_attn_in_place_argument_errors(ops):
+    from unimedvl_amd._lib import UmvError
+    nh, hd, T = 16, 72, 64
+    qkv = rnd((T, 3 * nh * hd), 7)
+    cu = torch.tensor([0, T], dtype=torch.int32).cuda()
+    kvl = torch.tensor([T], dtype=torch.int32).cuda()
+    out = torch.zeros((T, nh * hd), dtype=BF16, device="cuda")
+    vslab = ops.KVSlab(1, nh, 64, hd, "cuda", keys=False)
+    with pytest.raises(UmvError):      # a keys=False slab without packed K
+        ops.attention(qkv[:, :nh * hd], out, vslab, cu, kvl, nh, nh, hd, False, T, T)
+    with pytest.raises(UmvError):      # packed K is the non-causal, unsplit form
+        ops.attention(qkv[:, :nh * hd], out, vslab, cu, kvl, nh, nh, hd, True, T, T, k_packed=qkv[:, nh * hd:2 * nh * hd])
+    with pytest.raises(UmvError):      # V-only split goes with a keys=False slab only
+        ops.qkv_post(qkv, None, ops.KVSlab(1, nh, 64, hd, "cuda"), torch.zeros(T, dtype=torch.int32).cuda(),
+                     torch.arange(T, dtype=torch.int32).cuda(), None, nh, nh, hd)
+
+
 def test_attn_kernel_variants_bit_identical():
     """tools/attn_ab.py as a test: the per-wave streaming kernel (UMV_ATTN_SHARED=0), the LDS-shared kernel with one
     q-tile per wave (UMV_ATTN_TQ=1) and with two (UMV_ATTN_TQ=2) produce the same bits on every shape of the script."""

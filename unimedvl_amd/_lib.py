@@ -48,6 +48,7 @@ class AttnArgs(C.Structure):
         ("v_head_stride", C.c_int64), ("v_d_stride", C.c_int64),
         ("nseg", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("causal", C.c_int),
         ("max_q", C.c_int), ("max_kv", C.c_int), ("nsplit", C.c_int), ("workspace", C.c_void_p),
+        ("q_row_stride", C.c_int64), ("k_key_stride", C.c_int64),
     ]
 
 

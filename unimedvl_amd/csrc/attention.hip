@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     // Q fragments (B operand): lane (j,g) holds Q[row j][ks*32 + g*8 .. +8]
     bf16x8 qf[KS];
     {
-        const bf16_t* qp = a.q + ((int64_t)(q0 + (rvalid ? qi : 0)) * a.nq + head) * HD;
+        const bf16_t* qp = a.q + (int64_t)(q0 + (rvalid ? qi : 0)) * (a.q_row_stride ? a.q_row_stride : (int64_t)a.nq * HD) + head * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 32 + g * 8;
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
         int last_q = min(Lq - 1, qt * QPT + QPT - 1);
         kb_end = min(kb_end, Lk - Lq + last_q + 1);
     }
-    const bf16_t* kbase = a.k_slab + s * a.k_seg_stride + kh * a.k_head_stride;
+    const int64_t kstride = a.k_key_stride ? a.k_key_stride : HD;     // packed K (k_key_stride > 0): rows cu_q[s] .. of a [T, ...] buffer
+    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : s * a.k_seg_stride) + kh * a.k_head_stride;
     const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
 
     f32x4 o[DT];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-            const bf16_t* kp = kbase + (int64_t)key * HD;
+            const bf16_t* kp = kbase + (int64_t)min(key, Lk - 1) * kstride;   // keys past Lk are masked below: any valid row will do
 #pragma unroll
             for (int ks = 0; ks < (PREFETCH ? KS : 1); ++ks) {
                 const int d = ks * 32 + g * 8;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
                 for (int ks = 0; ks < KS; ++ks) st[t] = mfma16(kcur[t][ks], qf[ks], st[t]);
             } else {   // large head_dim: stream the K fragments through the MFMA chain
                 const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-                const bf16_t* kp = kbase + (int64_t)key * HD;
+                const bf16_t* kp = kbase + (int64_t)min(key, Lk - 1) * kstride;   // keys past Lk are masked below: any valid row will do
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int d = ks * 32 + g * 8;
@@ -278,6 +279,10 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     UMV_CHECK(a.nkv > 0 && a.nq % a.nkv == 0 && a.nq / a.nkv <= 16, UMV_ERR_ARG, "attn: bad head counts nq=%d nkv=%d", a.nq, a.nkv);
     UMV_CHECK(a.nsplit >= 1 && a.nsplit <= 32 && (a.nsplit == 1 || a.workspace), UMV_ERR_ARG, "attn: nsplit=%d (1..32) needs workspace", a.nsplit);
     UMV_CHECK((a.v_d_stride % 8) == 0, UMV_ERR_ARG, "attn: slab capacity must be a multiple of 8");
+    UMV_CHECK(a.q_row_stride >= 0 && a.k_key_stride >= 0 && (a.q_row_stride % 8) == 0 && (a.k_key_stride % 8) == 0 && (a.k_head_stride % 8) == 0,
+              UMV_ERR_ARG, "attn: q_row_stride / k_key_stride / k_head_stride must be non-negative multiples of 8 elements (16-byte fragment loads)");
+    UMV_CHECK(a.k_key_stride == 0 || (a.nsplit == 1 && !a.causal), UMV_ERR_UNSUPPORTED,
+              "attn: packed K (k_key_stride > 0) is the cache-less self-attention form: nsplit = 1, non-causal, kv_len[s] = cu_q[s+1] - cu_q[s]");
     if (a.nseg == 0 || a.max_q == 0) return UMV_OK;
     const int G = a.nq / a.nkv;
     const int QPT = 16 / G > 0 ? 16 / G : 1;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
         if (a.causal) e = min(Lk, Lk - Lq + min(Lq - 1, qt * QPT + QPT - 1) + 1);
         my_end[u] = active ? e : 0;
         wave_end = max(wave_end, my_end[u]);
-        const bf16_t* qp = a.q + ((int64_t)(q0 + (rvalid[u] ? qi[u] : 0)) * a.nq + head) * HD;
+        const bf16_t* qp = a.q + (int64_t)(q0 + (rvalid[u] ? qi[u] : 0)) * (a.q_row_stride ? a.q_row_stride : (int64_t)a.nq * HD) + head * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 32 + g * 8;
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
         blk_end = min(Lk, Lk - Lq + last_blk + 1);
     }
     const int nstages = (blk_end + 32 * NB - 1) / (32 * NB);
-    const bf16_t* kbase = a.k_slab + s * a.k_seg_stride + kh * a.k_head_stride;
+    const int64_t kstride = a.k_key_stride ? a.k_key_stride : HD;     // packed K (k_key_stride > 0): rows cu_q[s] .. of a [T, ...] buffer
+    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : s * a.k_seg_stride) + kh * a.k_head_stride;
     const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero_page);
     const int cap = (int)a.v_d_stride;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
                 const int t = ff / KS, ks = ff - t * KS;
                 const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
                 const int d = ks * 32 + g * 8;
-                p = (d < HD) ? kbase + (int64_t)min(key, Lk - 1) * HD + d : zero;
+                p = (d < HD) ? kbase + (int64_t)min(key, Lk - 1) * kstride + d : zero;
             } else {           // V^T fragment dt: row d = dt*16 + j, keys kb + g*8 .. +8
                 const int d = (ff - FK) * 16 + j;
                 const int col = kb + g * 8;

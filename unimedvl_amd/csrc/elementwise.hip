@@ -643,8 +643,10 @@ __global__ __launch_bounds__(256) void qkv_split_tile_kernel(umv_qkv_post_args a
     const int HD = a.hd, CH = HD / 8, nheads = a.nq + 2 * a.nkv;
     const int t0 = blockIdx.x * 8, nt = min(8, a.T - t0);
     const int q_ch = a.nq * CH, qk_ch = (a.nq + a.nkv) * CH, row_ch = nheads * CH, nv = a.nkv * HD;
-    for (int i = threadIdx.x; i < nt * row_ch; i += 256) {
-        const int tt = i / row_ch, c = i - tt * row_ch;
+    // q_out == null: V only - q and K stay where the GEMM wrote them (umv_attn_varlen's q_row_stride / k_key_stride form)
+    const int c_lo = a.q_out ? 0 : qk_ch, span = row_ch - c_lo;
+    for (int i = threadIdx.x; i < nt * span; i += 256) {
+        const int tt = i / span, c = c_lo + (i - tt * span);
         const int t = t0 + tt;
         const bf16x8 v = ldg_frag(a.qkv + (int64_t)t * nheads * HD + (int64_t)c * 8);
         if (c < q_ch) {
@@ -681,7 +683,10 @@ __global__ __launch_bounds__(256) void qkv_split_tile_kernel(umv_qkv_post_args a
 extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap, UMV_ERR_ARG, "qkv_post: null args");
     const umv_qkv_post_args& a = *ap;
-    UMV_CHECK((a.qkv || a.qkv_partials) && a.q_out && a.k_slab && a.vt_slab && a.tok_seg && a.tok_slot, UMV_ERR_ARG, "qkv_post: null pointer");
+    const bool v_only = !a.q_out && !a.k_slab;      // plain split of V only (no norm / RoPE, head_dim % 8 == 0): q and K are read in place
+    UMV_CHECK((a.qkv || a.qkv_partials) && (v_only || (a.q_out && a.k_slab)) && a.vt_slab && a.tok_seg && a.tok_slot, UMV_ERR_ARG, "qkv_post: null pointer");
+    UMV_CHECK(!v_only || (a.qkv && !a.q_norm_w && (a.hd % 8) == 0 && (size_t)8 * a.nkv * a.hd * sizeof(bf16_t) <= 64 * 1024), UMV_ERR_UNSUPPORTED,
+              "qkv_post: the V-only split needs bf16 qkv rows, no norm / RoPE and head_dim %% 8 == 0");
     UMV_CHECK(!a.qkv_partials || (a.q_norm_w && a.n_splits >= 1 && a.n_splits <= 64), UMV_ERR_ARG,
               "qkv_post: fp32 partial input needs the norm + RoPE path and 1 <= n_splits <= 64");
     UMV_CHECK(!a.q_norm_w || (a.k_norm_w && a.cos_tab && a.sin_tab && a.tok_pos), UMV_ERR_ARG, "qkv_post: norm without rope tables");

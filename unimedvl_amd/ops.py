@@ -377,9 +377,10 @@ class KVSlab:
 
     __slots__ = ("k", "vt", "nseg", "nkv", "cap", "hd")
 
-    def __init__(self, nseg, nkv, cap, hd, device):
+    def __init__(self, nseg, nkv, cap, hd, device, keys=True):
+        """keys=False: V^T only - K is read in place from a packed buffer (attention(..., k_packed=...))."""
         assert cap % 32 == 0
-        self.k = torch.zeros((nseg, nkv, cap, hd), dtype=BF16, device=device)
+        self.k = torch.zeros((nseg, nkv, cap, hd), dtype=BF16, device=device) if keys else None
         self.vt = torch.zeros((nseg, nkv, hd, cap), dtype=BF16, device=device)
         self.nseg, self.nkv, self.cap, self.hd = nseg, nkv, cap, hd
 
@@ -458,7 +459,10 @@ def residual_rmsnorm(partials, seq, w, eps, out):
 def qkv_post(qkv, q_out, slab, tok_seg, tok_slot, tok_pos, nq, nkv, hd, eps=1e-6, q_norm=None, k_norm=None,
              q_norm_gen=None, k_norm_gen=None, expert=None, cos_tab=None, sin_tab=None, T=None, fp32_chain=False,
              partials=None, bias=None):
-    """partials (fp32 [S, T, (nq+2nkv)*hd]) + bias: take the QKV row from a split-K GEMM instead of `qkv`."""
+    """partials (fp32 [S, T, (nq+2nkv)*hd]) + bias: take the QKV row from a split-K GEMM instead of `qkv`.
+    q_out=None with a keys=False slab: only V is split off (into V^T); q and K are then read in place by attention()."""
+    if (q_out is None) != (slab.k is None):
+        raise _lib.UmvError("qkv_post: q_out=None (V-only split) goes with a KVSlab(keys=False), and only with it")
     lib = _lib.load()
     if partials is None:
         _req(qkv, BF16, "qkv")
@@ -472,7 +476,7 @@ def qkv_post(qkv, q_out, slab, tok_seg, tok_slot, tok_pos, nq, nkv, hd, eps=1e-6
         n_splits=0 if partials is None else partials.shape[0],
         split_stride=0 if partials is None else partials.stride(0),
         qkv_bias=None if bias is None else bias.data_ptr(),
-        q_out=q_out.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(),
+        q_out=None if q_out is None else q_out.data_ptr(), k_slab=None if slab.k is None else slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(),
         tok_seg=tok_seg.data_ptr(), tok_slot=tok_slot.data_ptr(),
         tok_pos=None if tok_pos is None else tok_pos.data_ptr(),
         expert=None if expert is None else expert.data_ptr(),
@@ -489,14 +493,29 @@ def attn_workspace(nseg, nq, hd, max_q, nsplit, device):
     return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
 
 
-def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None):
+def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None, k_packed=None):
+    """q: [T, nq*hd] or [T, nq, hd] rows, possibly a column slice of a wider buffer (row stride = q.stride(0)).
+    k_packed: [T, nkv*hd] column slice holding K row-aligned with q (cache-less self-attention): the K slab is not read."""
     lib = _lib.load()
     _req(q, BF16, "q")
+    if q.stride(-1) != 1 or (q.dim() == 3 and q.stride(1) != hd):
+        raise _lib.UmvError("attention: q rows must be contiguous [nq * hd] runs")
+    strides = slab.strides()
+    if k_packed is not None:
+        _req(k_packed, BF16, "k_packed")
+        if k_packed.dim() != 2 or k_packed.stride(1) != 1 or k_packed.shape[0] != q.shape[0] or k_packed.shape[1] != nkv * hd:
+            raise _lib.UmvError("attention: k_packed must be a [T, nkv*hd] view with unit column stride")
+        k_ptr, k_key_stride = k_packed.data_ptr(), k_packed.stride(0)
+        strides["k_head_stride"] = hd
+    else:
+        if slab.k is None:
+            raise _lib.UmvError("attention: this KVSlab holds no keys (keys=False) - pass k_packed")
+        k_ptr, k_key_stride = slab.k.data_ptr(), 0
     a = AttnArgs(
         q=q.data_ptr(), out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
-        k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
+        k_slab=k_ptr, vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
         causal=int(bool(causal)), max_q=max_q, max_kv=max_kv, nsplit=nsplit,
-        workspace=None if workspace is None else workspace.data_ptr(), **slab.strides())
+        workspace=None if workspace is None else workspace.data_ptr(), q_row_stride=q.stride(0), k_key_stride=k_key_stride, **strides)
     check(lib.umv_attn_varlen(C.byref(a), _stream()), "umv_attn_varlen")
     return out
 

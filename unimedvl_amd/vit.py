@@ -57,17 +57,18 @@ class SiglipVisionModel:
         xb = ops.cast_pad(px, w.k_pad)                       # autocast's fp32->bf16 cast of the pixels
         h = ops.gemm(xb, w.patch)                            # patch embedding (siglip_navit.py:190)
         ops.add_rows(h, h, table=w.pos, idx=pos_ids)         # + position_embedding(ids) (:192)
-        slab = ops.KVSlab(nimg, nh, (max(lens) + 31) // 32 * 32, hd, dev)
+        # no cache in this tower: q and K are read by the attention kernel where the QKV GEMM wrote them (column slices of
+        # `qkv`); only V needs its transposed slab
+        slab = ops.KVSlab(nimg, nh, (max(lens) + 31) // 32 * 32, hd, dev, keys=False)
         x = torch.empty_like(h)
         qkv = torch.empty((N, 3 * h_dim), dtype=BF16, device=dev)
-        q = torch.empty((N, nh, hd), dtype=BF16, device=dev)
         o = torch.empty((N, h_dim), dtype=BF16, device=dev)
         a = torch.empty((N, cfg.vit_inter), dtype=BF16, device=dev)
         for lw in w.layers:
             ops.layernorm(h, lw.ln1_w, lw.ln1_b, cfg.ln_eps, out=x)
             ops.gemm(x, lw.qkv, out=qkv)
-            ops.qkv_post(qkv, q, slab, meta[0], meta[1], None, nh, nh, hd)
-            ops.attention(q, o, slab, cu_q, kv_len, nh, nh, hd, False, max_seqlen, max_seqlen)
+            ops.qkv_post(qkv, None, slab, meta[0], meta[1], None, nh, nh, hd)
+            ops.attention(qkv[:, :h_dim], o, slab, cu_q, kv_len, nh, nh, hd, False, max_seqlen, max_seqlen, k_packed=qkv[:, h_dim:2 * h_dim])
             ops.gemm(o, lw.out, out=h, residual=h)
             ops.layernorm(h, lw.ln2_w, lw.ln2_b, cfg.ln_eps, out=x)
             ops.gemm(x, lw.fc1, out=a, act="gelu_tanh")
