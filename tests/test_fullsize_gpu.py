@@ -71,6 +71,7 @@ def test_decode_step_equals_prefill(full):
         sess.commit()
         assert c.lens == [kvl[b]]
     worst_k = worst_v = 0.0
+    worst_by_layer = {}
     for l in (0, 1, cfg.layers // 2, cfg.layers - 1):
         ka, va = whole.packed_keys(l).float(), whole.packed_values(l).float()       # [sum_len, kvh, hd]
         off = 0
@@ -81,15 +82,20 @@ def test_decode_step_equals_prefill(full):
                 d = (a_ - b_).abs()
                 scale = a_.abs().max().item()
                 rel_last, rel_all = d[-1].max().item() / scale, d.max().item() / scale
-                # measured: <= 0.03 at the last layer (bf16 roundings of two different kernel paths through 28 layers)
-                assert rel_all <= 0.08, f"layer {l} sample {b} {what}: {rel_all:.4f} of the value range"
-                assert d.mean().item() <= 0.01 * scale
+                # two different kernel paths (tiled MFMA GEMMs + prefill attention vs weight-streaming split-K GEMMs + split-KV
+                # attention) round to bf16 at the same places but sum in different orders: the deviation grows with depth.
+                # Measured worst element over the samples: layer 0: 0.0003, layer 1: 0.009, layer 14: 0.027, layer 27: 0.036 of the range
+                bound = {0: 0.002, 1: 0.016}.get(l, 0.045 if l < cfg.layers - 1 else 0.06)
+                worst_by_layer[l] = max(worst_by_layer.get(l, 0.0), rel_all)
+                assert rel_all <= bound, f"layer {l} sample {b} {what}: {rel_all:.4f} of the value range (bound {bound})"
+                assert d.mean().item() <= (0.002 if l < 2 else 0.01) * scale
                 if what == "K":
                     worst_k = max(worst_k, rel_last)
                 else:
                     worst_v = max(worst_v, rel_last)
             off += n
-    print(f"decode-vs-prefill last-token K / V deviation: {worst_k:.4f} / {worst_v:.4f} of the value range")
+    print(f"decode-vs-prefill last-token K / V deviation: {worst_k:.4f} / {worst_v:.4f} of the value range; worst element by layer "
+          + ", ".join(f"{l}: {v:.4f}" for l, v in sorted(worst_by_layer.items())))
     # and the next-token logits from either cache
     gi = model.prepare_start_tokens(kvl, rope, ids)
     _, la = model.generate_text(past_key_values=deepcopy(whole), max_length=1, return_logits=True, **gi)
