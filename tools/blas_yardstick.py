@@ -31,7 +31,7 @@ for M, N, K in [(8208, 4608, 3584), (8208, 3584, 3584), (8208, 18944, 3584), (82
     w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF16)
     lin = ops.PackedLinear.from_weight(w)
     out = torch.empty(M, N, device="cuda", dtype=BF16)
-    us_lib = t(lambda: torch.matmul(x, w.t(), out=out)) if not os.environ.get("UMV_GEMM_TILE") else float("nan")
+    us_lib = t(lambda: torch.matmul(x, w.t(), out=out)) if not os.environ.get("UMV_NO_LIB") else float("nan")
     us_umv = t(lambda: ops.gemm(x, lin, out=out))
     fl = 2.0 * M * N * K
     print(f"M={M:5d} N={N:6d} K={K:6d}  torch.matmul {us_lib:8.1f} us {fl / us_lib / 1e6:7.1f} TF/s   umv_gemm_bf16 {us_umv:8.1f} us {fl / us_umv / 1e6:7.1f} TF/s")

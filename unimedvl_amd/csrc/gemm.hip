@@ -688,10 +688,19 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_frag(bf16x8& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
-// read r of NRD goes right after MFMA number (r * NMMA) / NRD of NMMA: evenly spread, first one after the first MFMA
+// read r of NRD goes right after MFMA number (r * SPAN) / NRD, SPAN = 3/4 of the step's MFMAs: evenly spread over the first three
+// quarters, first one after the first MFMA, so that the last quarter's MFMAs cover the latency of the last reads before the
+// step's closing s_waitcnt lgkmcnt(0) (spread over the whole step the last read sat 2 MFMAs before that wait)
+// piece p of n_pieces goes behind MFMA floor((2p + 1) * n_mma / (2 * n_pieces)): evenly spread, never behind the last MFMA
+__host__ __device__ constexpr int dma_slot(int i, int n_mma, int n_pieces) {
+    for (int p = 0; p < n_pieces; ++p)
+        if (((2 * p + 1) * n_mma) / (2 * n_pieces) == i) return p;
+    return -1;
+}
 constexpr int interleave_slot(int i, int nmma, int nrd) {
+    const int span = (nmma * 3 / 4 >= nrd) ? nmma * 3 / 4 : nmma;
     for (int r = 0; r < nrd; ++r)
-        if ((r * nmma) / nrd == i) return r;
+        if ((r * span) / nrd == i) return r;
     return -1;
 }
 __device__ __forceinline__ void mfma16_asm(f32x4& c, const bf16x8& a, const bf16x8& b) {
@@ -823,8 +832,14 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int p = 0; p < NBUF - 1; ++p)
+    for (int p = 0; p < NBUF - 1; ++p) {
         if (p < nsteps) stage(p, p);
+        else if (SCHED == 1) {       // (K < 96) keep the number of pieces in flight uniform: see the interleaved loop below
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_t)(smem + p * BUF + (wave * TPW + i) * 1024), 16, 0, 0);
+        }
+    }
     if constexpr (SCHED == 1) {
         // Interleaved schedule (KTS == 1).  With the plain loop every wave leaves the barrier, issues its 12 ds_read_b128
         // at once and only then its 32 MFMAs: the 8 waves' 96 KiB of fragment reads keep the LDS pipe busy for ~768
@@ -848,7 +863,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
             for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
         };
-        wait_tiles(min(NBUF - 2, nsteps - 1));
+        wait_tiles(NBUF - 2);
         __builtin_amdgcn_s_barrier();
         static_for<0, TN>([&](auto T) {
             constexpr int t = decltype(T)::value;
@@ -861,10 +876,38 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         land(wfA, xfA);
         constexpr int NRD = TN + TM, NMMA = TN * TM;
         static_assert(SCHED != 1 || NRD <= NMMA, "at most one fragment read per MFMA");
+        // The TPW LDS-DMA pieces of tile step + NBUF - 1 are issued BETWEEN the MFMAs as well, one every NMMA / TPW MFMAs.
+        // Issued in a burst behind the barrier (as the fragment reads once were) they keep the wave off the matrix pipe for
+        // TPW x 100-185 cycles per k-step (the guide's price of a piece inside a busy phase) while its twin on the SIMD, in
+        // lockstep, does the same.  That tile's buffer has been free since the barrier of the step before, and the counted
+        // waits only need the pieces to be issued before the next step's wait: placement inside the step is free.  One
+        // sequence for every step: the ragged last tile swaps its source pointers in before the sequence, and the last
+        // NBUF - 1 steps, which have nothing left to stage, copy the zero page into the (free) buffer so that the count of
+        // pieces in flight stays the same at every wait.
+        static_assert(SCHED != 1 || TPW <= NMMA, "at most one DMA piece per MFMA");
         auto body = [&](int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
-            if (step + 1 < nsteps) wait_tiles(min(NBUF - 3, nsteps - 2 - step));      // tile step+1 landed (mine)
+            wait_tiles(NBUF - 3);                                        // tile step+1 landed (mine); tile step+2's pieces may fly
             __builtin_amdgcn_s_barrier();                                // ... everyone's; and tile step-1's buffer is free
-            if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
+            const int st = step + NBUF - 1;                              // the tile staged during this step
+            if (st >= nsteps) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) { cur[i] = zero; bump[i] = 0; }
+            } else if (ragged && st == nsteps - 1) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int f = wave * TPW + i;
+                    if (f < WTILES) {
+                        const int kt = st * KTS + f % KTS;
+                        cur[i] = (tvalid[i] && kt < KTL) ? src[i] + (int64_t)st * (KTS * 512) : zero;
+                    } else {
+                        const int kt = st * KTS + (f - WTILES) % KTS;
+                        const int k = (kt0 + kt) * 32 + g * 8;
+                        cur[i] = (kt < KTL && k < a.K) ? src[i] + (int64_t)st * (KTS * 32) : zero;
+                    }
+                    bump[i] = 0;
+                }
+            }
+            char* dma_dst = smem + (st % NBUF) * BUF + wave * TPW * 1024;
             // the reads of the last step fetch a tile nobody uses (the buffer exists): no branch inside the sequence
             const uint32_t nb = lds0 + ((step + 1) % NBUF) * BUF;
             const uint32_t wa = nb + woff, xa = nb + xoff;
@@ -874,6 +917,13 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                 constexpr int rd = interleave_slot(i, NMMA, NRD);   // the read (if any) that follows MFMA i
                 if constexpr (rd >= 0 && rd < TN) lds_read_frag<(rd < TN ? rd : 0) * 1024>(wnx[rd < TN ? rd : 0], wa);
                 else if constexpr (rd >= TN) lds_read_frag<(rd >= TN ? rd - TN : 0) * 1024>(xnx[rd >= TN ? rd - TN : 0], xa);
+                constexpr int pc = dma_slot(i, NMMA, TPW);          // the DMA piece (if any) that follows MFMA i
+                if constexpr (pc >= 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_global_load_lds((const void*)cur[pc], (lds_ptr_t)(dma_dst + pc * 1024), 16, 0, 0);
+                    cur[pc] += bump[pc];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             });
             land(wnx, xnx);
         };
@@ -881,6 +931,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             body(step, wfA, xfA, wfB, xfB);
             if (step + 1 < nsteps) body(step + 1, wfB, xfB, wfA, xfA);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing zero-page pieces: the epilogue reuses the buffers
         // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> VALU-read wait states by hand
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
@@ -1114,8 +1165,6 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 335) return launch_tiled<4, 1, 2, 2, 2, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 64, 3 buffers (60 KiB, 2 WG/CU)
     if (cfg == 364) return launch_tiled<4, 1, 2, 4, 2, 3>(a, KT, NTT, s);      // 128(n) x 64(m) x 64, 3 buffers (72 KiB)
     if (cfg == 3128) return launch_tiled<4, 1, 2, 8, 2, 3>(a, KT, NTT, s);     // 128(n) x 128(m) x 64, 3 buffers (96 KiB)
-    if (cfg == 272) return launch_tiled<2, 2, 4, 8, 1, 3, 1>(a, KT, NTT, s);   // 128(n) x 256(m) x 32, 4 waves of 64 x 128, 3 buffers (72 KiB): 2 WG/CU
-    if (cfg == 274) return launch_tiled<2, 2, 8, 4, 1, 3, 1>(a, KT, NTT, s);   // 256(n) x 128(m) x 32, 4 waves of 128 x 64, 3 buffers (72 KiB): 2 WG/CU
     if (cfg == 256) return launch_tiled<2, 4, 8, 4, 1, 4>(a, KT, NTT, s);      // 256x256x32, 4 buffers (128 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
