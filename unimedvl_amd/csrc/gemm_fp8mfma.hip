@@ -143,6 +143,13 @@ __device__ __forceinline__ i32x8 frag8(const u32x4& lo, const u32x4& hi) {
     return (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 }
 
+// piece p of n_pieces goes behind MFMA floor((2p + 1) * span / (2 * n_pieces)) of the step's first `span` MFMAs
+__host__ __device__ constexpr int dma_slot8(int i, int span, int n_pieces) {
+    for (int p = 0; p < n_pieces; ++p)
+        if (((2 * p + 1) * span) / (2 * n_pieces) == i) return p;
+    return -1;
+}
+
 template <int WN, int WM, int TN, int TM, int NBUF>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_args a, int KT, int NTT, int mblocks, int nblocks, int gn) {
     constexpr int NW = WN * WM;
@@ -191,31 +198,41 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
         }
     }
     const uint8_t* zero = reinterpret_cast<const uint8_t*>(g_zero_page8);
-    auto stage = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int f = wave * TPW + i;
-            const uint8_t* p = tvalid[i] ? src[i] + (int64_t)kt * (f < WPL ? 2048 : 128) : zero;
-            __builtin_amdgcn_global_load_lds((const void*)p, (lds8_ptr_t)(smem + buf * BUF + f * 1024), 16, 0, 0);
-        }
-    };
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // With >= 3 buffers the LDS-DMA pieces of k-step kt + NBUF - 1 are issued BETWEEN the MFMAs of step kt (as in
+    // gemm_tiled_kernel: in a burst behind the barrier the TPW pieces keep both lockstep waves of a SIMD off the matrix pipe
+    // for TPW x 100-185 cycles; 2048 x 3584 x 18944: 165 -> 154 us); steps past the end copy the zero page, so that every
+    // counted wait sees the same number of pieces in flight.  With two buffers (the 256 x 256 tile) a piece issued inside the
+    // step has less than a step to land before the next step's vmcnt(0): measured 2-5 % slower even confined to the first
+    // half of the MFMAs, so that tile keeps the burst.
+    auto piece = [&](int kt, int buf, int i) {
+        const int f = wave * TPW + i;
+        const uint8_t* p = (tvalid[i] && kt < KT) ? src[i] + (int64_t)kt * (f < WPL ? 2048 : 128) : zero;
+        __builtin_amdgcn_global_load_lds((const void*)p, (lds8_ptr_t)(smem + buf * BUF + f * 1024), 16, 0, 0);
+    };
 #pragma unroll
     for (int p = 0; p < NBUF - 1; ++p)
-        if (p < KT) stage(p, p);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) piece(p, p, i);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds8_ptr_t)smem;
     const int one = 0x7f7f7f7f;    // E8M0 scale 2^0 in every byte
+    constexpr int NMMA = TN * TM, DMA_SPAN = NMMA;
+    constexpr bool DMA_IN = NBUF >= 3;
+    static_assert(TPW <= DMA_SPAN, "at most one DMA piece per MFMA");
     for (int kt = 0; kt < KT; ++kt) {
-        const int ahead = min(NBUF - 2, KT - 1 - kt);   // k-steps still allowed in flight behind step kt
-        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+        if (DMA_IN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * TPW) : "memory");   // step kt landed (mine); newer ones fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + NBUF - 1 < KT) stage(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
+        const int kst = kt + NBUF - 1, bst = kst % NBUF;
+        if constexpr (!DMA_IN) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) piece(kst, bst, i);      // (also past the end: the zero page, into the buffer just vacated)
+        }
         // Hand-ordered step.  Left to the compiler, every wave issues its 2 (TM + TN) ds_read_b128 right after the barrier
         // and then its TN x TM MFMAs: the 8 waves' 192 KiB of reads (~1500 LDS cycles) and the ~2000 MFMA cycles per SIMD
         // add up (MfmaUtil 47 %).  Here only the x fragments and the first two W fragments are requested up front; the W
@@ -250,9 +267,16 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
                     lds_read16<(t + 2) * 2048>(wlo[(t + 2) % 3], wb);
                     lds_read16<(t + 2) * 2048 + 1024>(whi[(t + 2) % 3], wb);
                 }
+                constexpr int pc = DMA_IN ? dma_slot8(t * TM + j, DMA_SPAN, TPW) : -1;       // the DMA piece (if any) behind this MFMA
+                if constexpr (pc >= 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(kst, bst, pc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             });
         });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing zero-page pieces: the epilogue reuses the buffers
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs are opaque to the hazard recogniser: XDL write -> VALU read
 #pragma unroll
     for (int t = 0; t < TN; ++t)
