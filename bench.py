@@ -310,7 +310,8 @@ def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128,
             cfg_text_key_values_lens=gt["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
             cfg_img_packed_position_ids=gim["cfg_packed_position_ids"], cfg_img_packed_query_indexes=gim["cfg_packed_query_indexes"],
             cfg_img_key_values_lens=gim["cfg_key_values_lens"], cfg_img_packed_key_value_indexes=gim["cfg_packed_key_value_indexes"])
-        return [vae.decode_tokens_to_uint8(l, (hw, hw), model.latent_downsample, model.latent_patch_size) for l in lat]
+        # same-shape images go through the VAE decoder as one batch (bit-identical per image, tests/test_vae_gpu.py)
+        return list(vae.decode_tokens_batch_to_uint8(lat, (hw, hw), model.latent_downsample, model.latent_patch_size))
     once(3)                                    # warm-up (allocator, lazy module load)
     torch.cuda.synchronize()
     if dist is not None:

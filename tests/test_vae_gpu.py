@@ -123,6 +123,56 @@ def test_t2i_pixels_vs_reference(vae, tiny_weights):
         f"pixels: {100 * (diff <= 4).float().mean().item():.2f}% within 4, max {diff.max().item()}"
 
 
+def test_batched_decode_matches_single(vae, tiny_weights):
+    """decode_tokens_batch_to_uint8 (the bench's T2I leg decodes its images of one shape in one pass) against
+    decode_tokens_to_uint8 image by image: convolutions, GroupNorm(32) and the mid-block attention are per sample
+    (autoencoder.py:240-257), so the only difference is which GEMM kernel the 1x1 convolutions / attention projections land on
+    (B * H * W rows: at this toy size one image is <= 64 rows = the weight-streaming kernel, four are the tiled one - another
+    fp32 summation order, amplified by ~30 bf16 stages).  Here: the file's pixel tolerance (<= 4 grey levels, >= 99 % of the pixels
+    identical); at real sizes: bit for bit (next test)."""
+    g = load_golden("t2i")
+    H, W = g["image_shape"].tolist()
+    cfg = tiny_weights[0]
+    down = 2 ** (len(cfg["vae_mult"]) - 1) * cfg["latent_patch"]
+    lat0 = g["latent_global"].float()
+    gen = torch.Generator().manual_seed(11)
+    lats = [lat0, lat0 + 0.3 * torch.randn(lat0.shape, generator=gen), -lat0, 0.5 * torch.randn(lat0.shape, generator=gen)]
+    batch = vae.decode_tokens_batch_to_uint8(lats, (H, W), down, cfg["latent_patch"]).cpu()
+    assert batch.shape[0] == 4 and batch.dtype == torch.uint8
+    for b, lt in enumerate(lats):
+        single = vae.decode_tokens_to_uint8(lt, (H, W), down, cfg["latent_patch"]).cpu()
+        d = (batch[b].int() - single.int()).abs()
+        assert d.max().item() <= 4 and (d == 0).float().mean().item() >= 0.99, f"image {b}: max {d.max().item()}"
+    assert not torch.equal(batch[0], batch[2])
+
+
+def test_batched_decode_bit_identical_at_full_size():
+    """the full-size decoder (128 / 256 / 512 channels, 16 latent channels) on four 256 x 256 images: one batched pass == four
+    single passes, bit for bit (every GEMM-shaped op has >= 1024 rows either way: same kernels, same summation order)."""
+    import math
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.shapes import vae_shapes
+    from unimedvl_amd.vae import AutoEncoder
+    cfg = UniMedVLConfig()
+    dev = torch.device("cuda", 0)
+    shapes = vae_shapes(cfg.to_dict())
+    gen = torch.Generator(device=dev).manual_seed(4321)
+
+    def vget(name):
+        shp = shapes[name]
+        if len(shp) == 1:
+            return torch.ones(shp, device=dev, dtype=BF16) if name.endswith("weight") else torch.zeros(shp, device=dev, dtype=BF16)
+        return (torch.randn(shp, device=dev, generator=gen) / math.sqrt(math.prod(shp[1:]))).to(BF16)
+    full = AutoEncoder(cfg, vget, device=dev)
+    hw, down, patch = 256, 16, 2
+    lats = [torch.randn((hw // down) ** 2, patch * patch * full.z, device=dev, generator=gen) for _ in range(4)]
+    batch = full.decode_tokens_batch_to_uint8(lats, (hw, hw), down, patch)
+    assert batch.shape == (4, hw, hw, 3)
+    for b, lt in enumerate(lats):
+        assert torch.equal(batch[b], full.decode_tokens_to_uint8(lt, (hw, hw), down, patch)), f"image {b}"
+    assert batch.float().std().item() > 1.0
+
+
 def test_edit_prefill_vs_reference(vae, tiny_weights):
     from unimedvl_amd.bagel import Bagel
     from unimedvl_amd.config import UniMedVLConfig

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(WN * WM * 64) void conv_tiled_kernel(const bf16_t* 
         }
     }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_v);
+    const bool cin32 = (geo.Cin & 31) == 0;
     auto stage = [&](int step, int buf) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -222,7 +223,17 @@ __global__ __launch_bounds__(WN * WM * 64) void conv_tiled_kernel(const bf16_t* 
                 const int kt = step * KTS + (f - WTILES) % KTS;
                 const int k = kt * 32 + g * 8;
                 if (k < K) {
-                    const int tap = k / geo.Cin, ci = k - tap * geo.Cin;
+                    // Cin % 32 == 0 (every conv of the VAE but conv_in): a 32-wide k-tile lies inside one filter tap, so the tap and
+                    // its (ky, kx) are wave-uniform - scalar divisions instead of ~60 VALU instructions per staged piece
+                    int tap, ci;
+                    if (cin32) {
+                        const int tu = __builtin_amdgcn_readfirstlane((kt * 32) / geo.Cin);
+                        tap = tu;
+                        ci = k - tu * geo.Cin;
+                    } else {
+                        tap = k / geo.Cin;
+                        ci = k - tap * geo.Cin;
+                    }
                     const int ky = tap / geo.ks, kx = tap - ky * geo.ks;
                     int iy, ix;
                     bool ok;
@@ -276,26 +287,51 @@ __global__ __launch_bounds__(WN * WM * 64) void conv_tiled_kernel(const bf16_t* 
                 for (int j = 0; j < TM; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
         }
     }
-    // epilogue: + bias -> bf16 ; (+ residual -> bf16); 4 consecutive output channels per lane
+    // epilogue: + bias -> bf16 ; (+ residual -> bf16); 4 consecutive output channels per lane (bias once per channel group,
+    // bias / residual as 8-byte loads when the four channels exist: Cout % 4 == 0 makes every such address 8-byte aligned)
+    const bool vec4 = (geo.Cout & 3) == 0 && ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(out)) & 7) == 0;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + (wm * TM + j) * 16 + r;
-        if (m >= M) continue;
+    for (int t = 0; t < TN; ++t) {
+        const int n0 = (nt_base + t) * 16 + g * 4;
+        if (n0 >= geo.Cout) continue;
+        const bool full = vec4 && n0 + 3 < geo.Cout;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            if (full) {
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(bias + n0);
+                b4[0] = __uint_as_float(pk.x << 16); b4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+                b4[2] = __uint_as_float(pk.y << 16); b4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+            } else {
 #pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const int n0 = (nt_base + t) * 16 + g * 4;
-            if (n0 >= geo.Cout) continue;
+                for (int q = 0; q < 4; ++q) b4[q] = bf2f(bias[min(n0 + q, geo.Cout - 1)]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + (wm * TM + j) * 16 + r;
+            if (m >= M) continue;
             const float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
+            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (residual) {
+                const bf16_t* rp = residual + (int64_t)m * geo.Cout + n0;
+                if (full) {
+                    const u32x2 pk = *reinterpret_cast<const u32x2*>(rp);
+                    r4[0] = __uint_as_float(pk.x << 16); r4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+                    r4[2] = __uint_as_float(pk.y << 16); r4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r4[q] = bf2f(residual[(int64_t)m * geo.Cout + min(n0 + q, geo.Cout - 1)]);
+                }
+            }
             bf16_t o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = min(n0 + q, geo.Cout - 1);
-                float f = rbf(v[q] + (bias ? bf2f(bias[n]) : 0.f));
-                if (residual) f = rbf(f + bf2f(residual[(int64_t)m * geo.Cout + n]));
+                float f = rbf(bias ? v[q] + b4[q] : v[q] + 0.f);
+                if (residual) f = rbf(f + r4[q]);
                 o[q] = f2bf(f);
             }
             bf16_t* dst = out + (int64_t)m * geo.Cout + n0;
-            if (n0 + 3 < geo.Cout && (geo.Cout & 3) == 0) {
+            if (full) {
                 u32x2 pk;
                 pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
                 pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);

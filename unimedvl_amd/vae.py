@@ -236,6 +236,28 @@ class AutoEncoder:
         return self.decoder(z)
 
     @ops.on_device
+    def decode_tokens_batch_to_uint8(self, latents, image_shape, latent_downsample, patch):
+        """decode_tokens_to_uint8 for several latents of ONE image shape in one pass through the decoder: [B,H,W,3] uint8.
+        Convolutions, GroupNorm and the mid-block attention are per sample, so every image equals its own
+        decode_tokens_to_uint8 - bit for bit whenever the 1x1-convolution GEMMs take the same kernel either way (>= 65 rows
+        per image, i.e. any real size; tests/test_vae_gpu.py).  The decoder's low-resolution levels are tiny grids for one
+        image (a 32 x 32 x 512 convolution is 64 workgroups of a 72-step chain: 150 us each on 256 CUs); a batch fills them:
+        four 256 x 256 images 27.3 -> 14.3 ms."""
+        H, W = image_shape
+        h, w = H // latent_downsample, W // latent_downsample
+        B = len(latents)
+        z = torch.empty((B, h * patch, w * patch, self.z), dtype=BF16, device=self.device)
+        for b, lt in enumerate(latents):
+            tok = lt.to(device=self.device, dtype=torch.float32).contiguous()
+            _lib.check(self._lib.umv_unpatchify_latent(tok.data_ptr(), z[b].data_ptr(), h, w, patch, self.z, self.scale_factor,
+                                                       self.shift_factor, _stream()), "umv_unpatchify_latent")
+        img = self.decoder(z)
+        _, Ho, Wo, Cs = img.shape
+        out = torch.empty((B, Ho, Wo, 3), dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.umv_pixels_to_u8(img.data_ptr(), out.data_ptr(), B * Ho * Wo, Cs, _stream()), "umv_pixels_to_u8")
+        return out
+
+    @ops.on_device
     def decode_tokens_to_uint8(self, latent_tokens, image_shape, latent_downsample, patch):
         img = self.decode_tokens(latent_tokens, image_shape, latent_downsample, patch)
         _, H, W, Cs = img.shape
