@@ -188,6 +188,47 @@ def test_gemm_splitk_partials_sum_to_fp32_reference(ops, M, N, K, S):
     check_bf16(got.to(BF16), ref.to(BF16), 1, 0.98, "split-K")
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 100, 2048, 266), (515, 1000, 1152, 268), (1000, 4300, 1152, 266), (777, 250, 1024, 270)])
+def test_gemm_lds_epilogue_ragged_and_unaligned(ops, M, N, K, tile, monkeypatch):
+    """The whole-row LDS epilogue of the tiled kernels (gemm_epilogue.h::epi_wave_tile_lds) on everything that leaves its 16-byte
+    fast path: N not a multiple of 8 (the last 16-byte chunk of a row is partial), an output / residual row pitch that is not a
+    multiple of 8 elements and a base pointer 2 bytes off 16-byte alignment (element stores, element residual loads), M with a
+    ragged last tile, row-indexed scatter.  Against fp32 matmul; rows and columns outside the result must stay untouched."""
+    monkeypatch.setenv("UMV_GEMM_TILE", str(tile))
+    import subprocess as sp
+    code = f"""
+import sys, math, torch
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+from unimedvl_amd import ops
+from test_kernel_branches_gpu import rnd, _mm, check_bf16, BF16
+M, N, K = {M}, {N}, {K}
+x = rnd((M, K), 1); w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
+lin = ops.PackedLinear.from_weight(w, b)
+T = M + 37
+pitch = N + 3                                   # odd pitch: no 8- or 16-byte aligned rows
+buf = torch.full((T * pitch + 1,), 7.0, dtype=BF16, device='cuda')
+out = buf[1:].view(T, pitch)[:, :N]             # base pointer 2 bytes past a 16-byte boundary
+resbuf = rnd((T, N + 5), 4)
+res = resbuf[:, :N]
+rows = torch.randperm(T, device='cuda')[:M].sort().values.to(torch.int32)
+xs = torch.zeros((T, K), dtype=BF16, device='cuda'); xs[rows.long()] = x
+ops.gemm(xs, lin, out=out, M=M, row_idx=rows, residual=res)
+ref = ((_mm(x, w) + b.float()).to(BF16).float() + res[rows.long()].float()).to(BF16)
+check_bf16(out[rows.long()].contiguous(), ref, 1, 0.97, 'ragged lds epilogue', two_roundings=True)
+keep = torch.ones(T, dtype=torch.bool, device='cuda'); keep[rows.long()] = False
+assert (out[keep] == 7.0).all(), 'rows outside row_idx were written'
+full = buf[1:].view(T, pitch)
+assert (full[:, N:] == 7.0).all() and float(buf[0]) == 7.0, 'columns beyond N were written'
+# and the plain (dense, aligned-base) form with a GELU epilogue on the same ragged N
+o2 = ops.gemm(x, lin, act='gelu_tanh')
+r2 = torch.nn.functional.gelu((_mm(x, w) + b.float()).to(BF16), approximate='tanh')
+check_bf16(o2, r2, 1, 0.97, 'ragged gelu', two_roundings=True)
+print('OK')
+"""
+    r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, UMV_GEMM_TILE=str(tile)))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 # ---------------------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, ks, vs, q_lens, causal):
     """flash-attn model in fp32 on the device: S = QK^T/sqrt(d) (+ bottom-right causal mask), fp32 softmax, P rounded to
