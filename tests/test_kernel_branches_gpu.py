@@ -97,6 +97,8 @@ TILED = [
     (1026, 4608, 3584, "bias", 268),          # single image span QKV
     (1026, 3584, 3584, "residual", 270),      # single image span o_proj
     (1026, 3584, 18944, "residual", 270),
+    (16500, 768, 3584, "residual", 266),      # >= 16k rows: two M super-blocks (33 + 32 m-blocks), each over all n-strips
+    (16500, 1280, 18944, "bias", 266),        # ... and nine of 8 (one of 1) at K = 18944
     (272, 4608, 3584, "bias", 64),            # 8 x 34 text tokens
     (300, 1152, 608, "bias", 64),             # short K (ViT patch embed, 588 padded to 608)
 ]

@@ -716,7 +716,7 @@ __device__ __forceinline__ void mfma16_asm(f32x4& c, const bf16x8& a, const bf16
 // SCHED = 1: the same pipeline with the MFMAs of tile t and the ds_reads of tile t+1 interleaved by hand (see below).
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn,
-                                                                  int ksplit) {
+                                                                  int ksplit, int ms) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;      // 1 KiB fragment tiles per k-step
@@ -731,8 +731,14 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     const int wn = wave % WN, wm = wave / WN;
     // XCD-aware order: blockIdx round-robins over the 8 XCDs, so give each XCD a contiguous run of
     // tiles (m fastest) and let its private L2 keep one W panel hot.
-    const int nwg = mblocks * nblocks;
-    int bid = blockIdx.x;
+    // M super-blocks (ms m-blocks each, launch_tiled sizes them to ~64 MB of x): all XCDs work through one super-block
+    // before the next, so that its x rows stay in the 256 MiB memory-side cache while the strips of W stream past - with 32
+    // images (M = 32 832, x = 235 MB, act = 1.2 GB) every strip of n-blocks otherwise re-streams all of x from HBM.
+    const int sb_tiles = ms * nblocks;
+    const int sb = (int)blockIdx.x / sb_tiles;                        // this workgroup's super-block ...
+    const int mb0 = sb * ms, mb_n = min(ms, mblocks - mb0);         // ... its m-blocks
+    const int nwg = mb_n * nblocks;
+    int bid = (int)blockIdx.x - sb * sb_tiles;
     {
         const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
@@ -742,9 +748,9 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     // (gn = 1 is plain m-fastest: every CU of the XCD streams its own x panel and only W is shared).
     int mblk, nblk;
     {
-        const int per = mblocks * gn, strip = bid / per, rem = bid - strip * per;
+        const int per = mb_n * gn, strip = bid / per, rem = bid - strip * per;
         const int w = min(gn, nblocks - strip * gn);
-        mblk = rem / w;
+        mblk = mb0 + rem / w;
         nblk = strip * gn + rem % w;
     }
     const int m0 = mblk * BM;
@@ -1042,8 +1048,18 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
     const int splits = a.k_splits > 1 ? a.k_splits : 1;
     const int ksplit = splits > 1 ? ((KT + splits - 1) / splits + KTS - 1) / KTS * KTS : 0;    // whole k-steps per split
+    // m-blocks per super-block: ~64 MB of x rows (UMV_GEMM_MSB overrides, tuning only; 0 = one super-block)
+    static int msb_env = -1;
+    if (msb_env < 0) { const char* e = getenv("UMV_GEMM_MSB"); msb_env = e ? atoi(e) : -2; }
+    int ms = (int)(((int64_t)64 << 20) / ((int64_t)BM * a.K * 2));
+    ms = ms < 8 ? 8 : ms;
+    if ((int64_t)mblocks * BM < 16384) ms = mblocks;   // measured (us, on / off): M = 32 832 gate/up 7040 / 7480, down 3880 / 4070, qkv 1013 / 1056;
+                                                       // M = 16 416 down 1975 / 2010, gate/up 3543 / 3528; M = 8208 down 1062 / 1047: off below 16k rows
+    if (msb_env >= 0) ms = msb_env == 0 ? mblocks : msb_env;
+    if (ms > mblocks || ms * 3 / 2 >= mblocks) ms = mblocks;        // a short second super-block is not worth a second pass over W
+    else ms = (mblocks + (mblocks + ms - 1) / ms - 1) / ((mblocks + ms - 1) / ms);   // equal super-blocks: no stub at the end
     hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>), dim3(mblocks * nblocks, splits), dim3(WN * WM * 64), lds, s, a,
-                       KT, NTT, mblocks, nblocks, raster_gn(), ksplit);
+                       KT, NTT, mblocks, nblocks, raster_gn(), ksplit, ms);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
