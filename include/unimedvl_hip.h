@@ -98,14 +98,6 @@ int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
  * Lets the parity tests assert that a shape reaches the kernel variant it is meant to pin. */
 int umv_gemm_tile_config(int M, int N, int K);
 
-/* Generic consumer of split-K partial sums (umv_gemm_bf16 with k_splits > 1 leaves raw fp32 partial sums [n_splits][M][N],
- * row m compact): out[row_idx[m]] = epilogue(sum of the splits in order 0..S-1), with the epilogue fields of `a` (bias,
- * activation, residual, row_idx, out, ldo - x, wp, K are ignored) and the roundings of the unsplit GEMM (F.linear -> bf16 ->
- * activation -> bf16 -> + residual -> bf16).  The decode step has its own fused consumers (umv_qkv_post,
- * umv_residual_rmsnorm_bf16); this one serves short prefills (65..512 rows), whose N = 3584 / 4608 GEMMs are too few tiles to
- * fill the chip unsplit. */
-int umv_splitk_finish(const float* partials, int n_splits, int64_t split_stride, const umv_gemm_args* a, umv_stream_t stream);
-
 /* ------------------------------------------------------------------ fp8 weights (BASELINE.json configs[4]; no
  * reference counterpart: the reference only has bf16 weights, qwen2_navit.py:541-562 / modeling_qwen2.py:229-235)
  * Weight-only OCP e4m3 with one POWER-OF-TWO scale per output channel, s[n] = the smallest 2^e with

@@ -215,41 +215,3 @@ def test_decode_session_above_64_samples_matches_oracle(tiny_weights):
         ref = oracle.lm_head(h).float()
         pos = pos + 1
         assert (runs[0][1][s] - ref).abs().max() <= 0.25, f"step {s}"
-
-
-@pytest.mark.parametrize("M,N,K", [(272, 3584, 18944), (272, 3584, 3584), (130, 3584, 18944), (512, 3584, 18944), (100, 4608, 3584)])
-def test_short_prefill_auto_split_matches_unsplit_and_fp32(M, N, K, monkeypatch):
-    """ops.gemm splits K for the tiled GEMMs of a short prefill (65..512 rows, N <= 8192: 8 x 34 text tokens behind 8 images,
-    bagel.py:470-521 -> qwen2_navit.py Qwen2MLP / attention projections) and umv_splitk_finish finishes the rows (bias +
-    residual + row_idx scatter, roundings of the unsplit epilogue).  Against the unsplit kernel (different fp32 summation order:
-    <= 1 bf16 ulp of the larger operand, >= 98 % identical) and an fp32 reference; rows outside row_idx stay untouched."""
-    import torch
-    from unimedvl_amd import ops
-    BF16 = torch.bfloat16
-    g = torch.Generator().manual_seed(M * 7 + N + K)
-    T = M + 41
-    x = torch.randn(T, K, generator=g).to(BF16).cuda()
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF16).cuda()
-    b = torch.randn(N, generator=g).to(BF16).cuda()
-    rows = torch.randperm(T, generator=g)[:M].sort().values.to(torch.int32).cuda()
-    res = torch.randn(T, N, generator=g).to(BF16).cuda()
-    lin = ops.PackedLinear.from_weight(w, b)
-    assert ops._short_prefill_splits(M, lin, x.device) >= 2
-    outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("UMV_GEMM_SHORT_SPLITK", flag)
-        out = res.clone()
-        ops.gemm(x, lin, out=out, M=M, row_idx=rows, residual=out)
-        outs.append(out)
-    split, plain = outs
-    untouched = torch.ones(T, dtype=torch.bool, device="cuda")
-    untouched[rows.long()] = False
-    assert torch.equal(split[untouched], res[untouched]) and torch.equal(plain[untouched], res[untouched])
-    a, c = split[rows.long()].float(), plain[rows.long()].float()
-    assert (a == c).float().mean().item() >= 0.98
-    gm = (x[rows.long()].float() @ w.float().t() + b.float())
-    mag = torch.maximum(torch.maximum(gm.abs(), res[rows.long()].float().abs()), c.abs())
-    ulp = mag.clamp_min(2.0 ** -120).log2().floor().exp2() * 2.0 ** -7
-    assert ((a - c).abs() <= 2 * ulp * 1.001).all() and ((a - c).abs() > ulp * 1.001).float().mean().item() <= 1e-4
-    ref = (gm.to(BF16).float() + res[rows.long()].float()).to(BF16).float()
-    assert ((a - ref).abs() <= ulp * 1.001).float().mean().item() >= 0.9995

@@ -81,7 +81,6 @@ _SIGS = {
     "umv_gemm_fp8a8w": (C.c_int, [C.POINTER(Gemm8Args), C.c_void_p]),
     "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
     "umv_gemm_tile_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "umv_splitk_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.POINTER(GemmArgs), C.c_void_p]),
     "umv_attn_prefill_tq": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "umv_version": (C.c_int, []),
     "umv_last_error": (C.c_char_p, []),

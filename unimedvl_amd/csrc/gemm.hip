@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 16 + r;
         mok[j] = m < a.M;
-        orow[j] = (mok[j] && a.row_idx && !ksplit) ? (int64_t)a.row_idx[m] : (int64_t)m;   // partial sums are stored compact (row m)
+        orow[j] = (mok[j] && a.row_idx) ? (int64_t)a.row_idx[m] : (int64_t)m;
     }
     static_for<0, TN>([&](auto T) {
         constexpr int t = decltype(T)::value;
@@ -1079,51 +1079,6 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
 // 4-buffer tile with the interleaved schedule wins whenever it yields >= ~144 workgroups (885-1120 TF/s on the
 // prefill / flow / ViT shapes); below that the 256(n) x 128(m) interleaved tile (M ~ 2048: 920-1020 TF/s), then
 // 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
-// ----------------------------------------------------------------------------- generic consumer of split-K partial sums
-// out[row_idx[m]] = epilogue(sum_s partials[s][m]) with the splits added in order 0..S-1 (the order of umv_qkv_post /
-// umv_residual_rmsnorm_bf16, the decode step's consumers) and the roundings of the unsplit epilogue (epi_store4).  For the
-// GEMMs of a short prefill (8 x 34 text tokens = 272 rows): N = 3584 / 4608 gives 84-140 tiles for 256 CUs, each a serial
-// chain over all of K (down_proj: 592 k-steps) - 73 us per GEMM against 5-25 us of weight streaming.
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partials, int S, int64_t split_stride, int M, int N, EpiCtx e,
-                                                           const int32_t* __restrict__ row_idx) {
-    const int n4 = (N + 3) / 4;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)M * n4) return;
-    const int m = (int)(idx / n4), n0 = (int)(idx - (int64_t)m * n4) * 4;
-    const float* p = partials + (int64_t)m * N + n0;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n0 + 3 < N && (N & 3) == 0) {
-        f32x4 acc = *reinterpret_cast<const f32x4*>(p);
-        for (int s = 1; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s * split_stride);
-        v[0] = acc.x; v[1] = acc.y; v[2] = acc.z; v[3] = acc.w;
-    } else {
-        for (int j = 0; j < 4 && n0 + j < N; ++j) {
-            float acc = p[j];
-            for (int s = 1; s < S; ++s) acc += p[(int64_t)s * split_stride + j];
-            v[j] = acc;
-        }
-    }
-    const int64_t orow = row_idx ? (int64_t)row_idx[m] : (int64_t)m;
-    epi_store4(e, orow, n0, v[0], v[1], v[2], v[3]);
-}
-
-extern "C" int umv_splitk_finish(const float* partials, int n_splits, int64_t split_stride, const umv_gemm_args* ap, umv_stream_t stream) {
-    UMV_CHECK(partials && ap, UMV_ERR_ARG, "splitk_finish: null pointer");
-    const umv_gemm_args a = *ap;
-    UMV_CHECK(a.out && a.M >= 0 && a.N > 0 && n_splits >= 1 && n_splits <= 64 && split_stride >= (int64_t)a.M * a.N, UMV_ERR_ARG,
-              "splitk_finish: bad sizes (M=%d N=%d splits=%d stride=%lld)", a.M, a.N, n_splits, (long long)split_stride);
-    UMV_CHECK(!(a.epilogue & (UMV_EPI_SWIGLU | UMV_EPI_OUT_F32)), UMV_ERR_UNSUPPORTED, "splitk_finish: SwiGLU / fp32 outputs are not split");
-    UMV_CHECK(!(a.epilogue & UMV_EPI_BIAS) || a.bias, UMV_ERR_ARG, "splitk_finish: BIAS without bias pointer");
-    UMV_CHECK(!(a.epilogue & UMV_EPI_RESIDUAL) || a.residual, UMV_ERR_ARG, "splitk_finish: RESIDUAL without residual pointer");
-    if (a.M == 0) return UMV_OK;
-    EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
-    const int64_t items = (int64_t)a.M * ((a.N + 3) / 4);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, n_splits, split_stride,
-                       a.M, a.N, e, a.row_idx);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
-}
-
 // UMV_GEMM_TILE=<256|266|258|268|129|130|270|64> overrides (tuning only).
 // Exported so that tests can assert which kernel a shape is sent to (returns 0 for M <= 64: weight-streaming kernels).
 extern "C" int umv_gemm_tile_config(int M, int N, int K) {
@@ -1153,8 +1108,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(!(a.epilogue & UMV_EPI_SWIGLU) || (a.N % 32) == 0, UMV_ERR_ARG, "gemm: SWIGLU needs N %% 32 == 0");
     UMV_CHECK(!a.norm_w || (a.M <= 16 && a.K <= SK_WAVES * SK_XMAX * 32), UMV_ERR_UNSUPPORTED,
               "gemm: fused RMSNorm needs M <= 16 and K <= %d (got M=%d K=%d)", SK_WAVES * SK_XMAX * 32, a.M, a.K);
-    UMV_CHECK(a.k_splits <= 1 || (a.M <= 1024 && !a.norm_w && !(a.epilogue & UMV_EPI_SWIGLU) && a.tile_rows % 16 == 0 && a.split_stride > 0),
-              UMV_ERR_UNSUPPORTED, "gemm: split-K (k_splits=%d) is for few rows: M <= 1024, 16-row image, no SwiGLU / fused norm, "
+    UMV_CHECK(a.k_splits <= 1 || (a.M <= 128 && !a.norm_w && !(a.epilogue & UMV_EPI_SWIGLU) && a.tile_rows % 16 == 0 && a.split_stride > 0),
+              UMV_ERR_UNSUPPORTED, "gemm: split-K (k_splits=%d) is a decode mode: M <= 128, 16-row image, no SwiGLU / fused norm, "
               "split_stride > 0", a.k_splits);
     UMV_CHECK(a.k_splits <= 64, UMV_ERR_ARG, "gemm: k_splits %d > 64", a.k_splits);
     UMV_CHECK(!a.argmax_partial || (a.M <= 64 && a.k_splits <= 1 && !a.row_idx && !a.norm_w && (a.tile_rows == 0 || a.tile_rows == 16) &&

@@ -2,7 +2,6 @@
 streams only).  Every function launches a hand-written gfx950 kernel from
 libunimedvl_hip.so on torch's current stream; there is no fallback path."""
 import ctypes as C
-import os
 import functools
 
 import torch
@@ -218,26 +217,6 @@ def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_b
     return out
 
 
-_CUS = {}
-
-
-def _short_prefill_splits(M, lin, device):
-    """K split for the tiled GEMMs of a short prefill (65..512 rows, N <= 8192), whose 128 x 128 tiles are too few to fill the
-    chip and each a serial chain over all of K: as many splits as keep ONE workgroup per CU (measured on 272 x 3584 x 18944:
-    unsplit 151 us, 2 / 3 / 4 / 6 / 8 ways 111 / 83 / 113 / 94 / 108; 130 rows: 4 ways 66; 512 rows: 2 ways 114), at least 16
-    k-steps per split.  The summation order of a row then depends on the row count of the call - as it already does between the
-    weight-streaming (<= 64 rows) and the tiled kernels."""
-    if os.environ.get("UMV_GEMM_SHORT_SPLITK", "1") == "0" or not (64 < M <= 512) or lin.th != 16 or lin.swiglu or lin.N > 8192 or lin.K < 2048 \
-            or lin.N % 4 or lin.wp is None:
-        return 1
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _CUS:
-        _CUS[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
-    tiles = ((M + 127) // 128) * ((lin.N + 127) // 128)
-    s = min(8, _CUS[idx] // tiles, lin.K // 512)
-    return s if s >= 2 else 1
-
-
 def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
          norm_w=None, norm_eps=1e-6, act8=False, argmax_partial=None):
     """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
@@ -322,14 +301,6 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         row_idx=row_idx.data_ptr() if row_idx is not None else None,
         M=M, N=lin.N, K=lin.K, epilogue=flags,
         norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th, argmax_partial=amax)
-    S = _short_prefill_splits(M, lin, x.device) if (norm_w is None and amax is None and not out_f32) else 1
-    if S > 1:
-        # too few tiles to fill the chip: split K on the 128 x 128 tile (fp32 partial sums, rows compact), one small kernel
-        # finishes the rows with the epilogue of `a`
-        partials = torch.empty((S, M, lin.N), dtype=torch.float32, device=x.device)
-        gemm_splitk(x, lin, partials, S, M=M, row_idx=row_idx)
-        check(lib.umv_splitk_finish(partials.data_ptr(), S, partials.stride(0), C.byref(a), _stream()), "umv_splitk_finish")
-        return out
     check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
     return out
 
@@ -454,7 +425,7 @@ def fake_quantize_act(x, M=None, row_idx=None):
     return out
 
 
-def gemm_splitk(x, lin, partials, k_splits, *, M=None, row_idx=None):
+def gemm_splitk(x, lin, partials, k_splits, *, M=None):
     """Split-K decode GEMM (M <= 64): raw fp32 partial sums [k_splits, rows, N] into `partials`; the consumer
     (qkv_post(partials=...) / residual_rmsnorm) adds the splits and finishes the row."""
     lib = _lib.load()
@@ -464,8 +435,7 @@ def gemm_splitk(x, lin, partials, k_splits, *, M=None, row_idx=None):
     assert partials.dim() == 3 and partials.shape[0] == k_splits and partials.shape[2] == lin.N and partials.is_contiguous()
     assert lin.th == 16 and not lin.swiglu
     a = GemmArgs(x=x.data_ptr(), ldx=x.stride(0), wp=None if lin.wp is None else lin.wp.data_ptr(), out=partials.data_ptr(), ldo=lin.N,
-                 M=M, N=lin.N, K=lin.K, epilogue=0, tile_rows=0, k_splits=k_splits, split_stride=partials.stride(0),
-                 row_idx=None if row_idx is None else row_idx.data_ptr())     # x rows gathered through row_idx, partial rows compact
+                 M=M, N=lin.N, K=lin.K, epilogue=0, tile_rows=0, k_splits=k_splits, split_stride=partials.stride(0))
     if lin.w8 is not None:   # e4m3 image: same split, same consumers
         a.wp, a.w_scale = lin.w8.data_ptr(), lin.scale.data_ptr()
         check(lib.umv_gemm_fp8w(C.byref(a), _stream()), "umv_gemm_fp8w")
