@@ -84,8 +84,9 @@ def test_decode_step_equals_prefill(full):
                 rel_last, rel_all = d[-1].max().item() / scale, d.max().item() / scale
                 # two different kernel paths (tiled MFMA GEMMs + prefill attention vs weight-streaming split-K GEMMs + split-KV
                 # attention) round to bf16 at the same places but sum in different orders: the deviation grows with depth.
-                # Measured worst element over the samples: layer 0: 0.0003, layer 1: 0.009, layer 14: 0.027, layer 27: 0.036 of the range
-                bound = {0: 0.002, 1: 0.016}.get(l, 0.045 if l < cfg.layers - 1 else 0.06)
+                # Measured worst element over the samples: layer 0: 0.0003-0.003 (one bf16 ulp at the top of the range is 0.004),
+                # layer 1: 0.009, layer 14: 0.027, layer 27: 0.036 of the range
+                bound = {0: 0.006, 1: 0.016}.get(l, 0.045 if l < cfg.layers - 1 else 0.06)
                 worst_by_layer[l] = max(worst_by_layer.get(l, 0.0), rel_all)
                 assert rel_all <= bound, f"layer {l} sample {b} {what}: {rel_all:.4f} of the value range (bound {bound})"
                 assert d.mean().item() <= (0.002 if l < 2 else 0.01) * scale
