@@ -94,7 +94,8 @@ typedef struct {
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 /* Host-only query: the tiled-kernel configuration umv_gemm_bf16 picks for an M x N x K problem (0 for M <= 64, the
- * weight-streaming kernels; 266 = 256x256x32 interleaved, 268 = 256(n)x128(m), 270 = 128x128, 64 = 128(n)x64(m)x64).
+ * weight-streaming kernels; 266 = 256x256x32 interleaved, 268 = 256(n)x128(m), 384 = 384(n)x128(m), 270 = 128x128,
+ * 64 = 128(n)x64(m)x64).
  * Lets the parity tests assert that a shape reaches the kernel variant it is meant to pin. */
 int umv_gemm_tile_config(int M, int N, int K);
 

@@ -92,7 +92,10 @@ TILED = [
     (8208, 37888, 3584, "swiglu", 266),       # gate/up SwiGLU
     (8192, 3456, 1152, "bias", 266),          # ViT fused q/k/v
     (8192, 4304, 1152, "gelu", 266),          # ViT fc1 + GELU-tanh
-    (8192, 1152, 4304, "residual", 266),      # ViT fc2 (+ residual)
+    (8192, 1152, 4304, "residual", 384),      # ViT fc2 (+ residual): 3 x 384 columns, no padding
+    (8192, 1152, 1152, "residual", 384),      # ViT out-proj
+    (2064, 4608, 3584, "bias", 384),          # flow-pass QKV: 12 x 384 columns by 17 row blocks
+    (32768, 1152, 4304, "bias", 384),         # 32 images
     (2064, 37888, 3584, "swiglu", 266),       # flow pass gate/up
     (1026, 4608, 3584, "bias", 268),          # single image span QKV
     (1026, 3584, 3584, "residual", 270),      # single image span o_proj
@@ -137,7 +140,7 @@ def test_gemm_tiled_branch(ops, M, N, K, epi, cfg):
     check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}", two_roundings=(epi == "gelu"))
 
 
-@pytest.mark.parametrize("M,n_text,N,K,cfg", [(2064, 16, 4608, 3584, 266), (2064, 16, 3584, 18944, 268), (1032, 8, 4608, 3584, 268)])
+@pytest.mark.parametrize("M,n_text,N,K,cfg", [(2064, 16, 4608, 3584, 384), (8224, 16, 4608, 3584, 266), (2064, 16, 3584, 18944, 268), (1032, 8, 4608, 3584, 268)])
 def test_gemm_tiled_row_indexed_mot(ops, M, n_text, N, K, cfg):
     """MoT routing at flow-pass size (qwen2_navit.py:552-562,891-898): the latent rows go through the tiled kernel by a row
     index list, the marker-token rows through the weight-streaming kernel, into one output buffer."""

@@ -1079,7 +1079,7 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
 // 4-buffer tile with the interleaved schedule wins whenever it yields >= ~144 workgroups (885-1120 TF/s on the
 // prefill / flow / ViT shapes); below that the 256(n) x 128(m) interleaved tile (M ~ 2048: 920-1020 TF/s), then
 // 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
-// UMV_GEMM_TILE=<256|266|258|268|129|130|270|64> overrides (tuning only).
+// UMV_GEMM_TILE=<256|266|258|268|384|129|130|270|64> overrides (tuning only).
 // Exported so that tests can assert which kernel a shape is sent to (returns 0 for M <= 64: weight-streaming kernels).
 extern "C" int umv_gemm_tile_config(int M, int N, int K) {
     static int force = -1;
@@ -1090,6 +1090,14 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
     const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long wg258 = (long)((M + 127) / 128) * ((N + 255) / 256);
     if (K < 1024) return 64;              // short K: the 4-buffer prologue does not amortise
+    if (wg256 >= 144 && N % 384 == 0) {
+        // N = 1152 (SigLIP out / fc2) is 4.5 tiles of 256: 10 % padding and 160 tiles for 256 CUs.  As 3 x 384 columns by 128 rows
+        // it is 192 tiles of 3/4 the work: rounds x tile area decides (out 46.7 -> 37.3 us, fc2 103.8 -> 89.9; the fused q/k/v
+        // GEMM, N = 3456, stays on 256 x 256: 76 vs 95 us)
+        const long cus = 256, t384 = (long)((M + 127) / 128) * (N / 384);
+        const long c266 = (wg256 + cus - 1) / cus * 65536, c384 = (t384 + cus - 1) / cus * 49152;
+        if (c384 * 10 < c266 * 9) return 384;
+    }
     if (wg256 >= 144) return 266;
     if (wg258 >= 140) return 268;
     if (wg128 >= 128) return 270;
@@ -1186,6 +1194,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
     if (cfg == 266) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, MFMA / ds_read interleaved by hand
     if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
+    if (cfg == 384) return launch_tiled<4, 2, 6, 4, 1, 4, 1>(a, KT, NTT, s);   // 384(n)x128(m)x32, 8 waves of 96 x 64: N = 1152 = 3 x 384 without padding
     if (cfg == 270) return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 128x128x32, 4 waves, 4 buffers (64 KiB, 2 WG/CU), interleaved
     if (cfg == 258) return launch_tiled<4, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 256(n)x128(m)x32, 8 waves as 4x2 (96 KiB)
     return launch_tiled<2, 2, 4, 2, 2, 3>(a, KT, NTT, s);                      // 128(n) x 64(m) x 64, 3 buffers (72 KiB)

@@ -182,6 +182,14 @@ __device__ __forceinline__ void epi_swiglu4(const EpiCtx& e, int64_t orow, int c
 //            instruction covers 64/CH whole rows of the wave tile (256 contiguous bytes each at TN = 8).
 // Arithmetic and rounding points are those of epi_store4 / epi_swiglu4: results are bit-identical to the direct path.
 // sw (per column) / sx (per row), optional: dequantisation scales of the fp8 kernels, applied to the raw accumulator.
+// chunk -> physical chunk of a row: XOR with the row for power-of-two chunk counts, rotation by the row otherwise (the
+// 384-column tile: 12 / 6 chunks) - either way the 16 rows a ds_write_b64 touches spread over the banks
+template <int CH>
+__device__ __forceinline__ int epi_swz(int chunk, int row) {
+    if constexpr ((CH & (CH - 1)) == 0) return chunk ^ (row & (CH - 1));
+    else return (chunk + row) % CH;
+}
+
 template <int TN, int TM>
 __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[TN][TM], char* wreg, int lane, int m_wave0, int M,
                                                   const int32_t* __restrict__ row_idx, int nt_base, int NTT,
@@ -197,17 +205,17 @@ __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[
     }
     auto finish = [&](auto CHC, int col_base, int n_out) {
         constexpr int CH = decltype(CHC)::value;           // 16-byte chunks per row of the wave tile
-        constexpr int ROWB = CH * 16, RPI = 64 / CH, NI = TM * 16 / RPI;
+        constexpr int ROWB = CH * 16, RPI = 64 / CH, NI = (TM * 16 + RPI - 1) / RPI;   // (64 % CH lanes idle when CH is not a power of two)
         const int row_l = lane / CH, chunk = lane % CH;
         const int col0 = col_base + chunk * 8;
-        if (col0 >= n_out) return;
+        if (col0 >= n_out || row_l >= RPI) return;
         const bool full = col0 + 7 < n_out;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = i * RPI + row_l;
             const int m = m_wave0 + row;
-            if (m >= M) continue;
-            u32x4 v = *reinterpret_cast<const u32x4*>(wreg + row * ROWB + ((chunk ^ (row & (CH - 1))) << 4));
+            if (row >= TM * 16 || m >= M) continue;
+            u32x4 v = *reinterpret_cast<const u32x4*>(wreg + row * ROWB + (epi_swz<CH>(chunk, row) << 4));
             const int64_t orow = row_idx ? (int64_t)row_idx[m] : (int64_t)m;
             bf16_t* o = reinterpret_cast<bf16_t*>(e.out) + orow * e.ldo + col0;
             if (e.flags & UMV_EPI_RESIDUAL) {
@@ -265,7 +273,7 @@ __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[
                 pk.x = pack2bf(v[0], v[1]);
                 pk.y = pack2bf(v[2], v[3]);
                 const int chunk = 2 * p + (g >> 1);
-                *reinterpret_cast<u32x2*>(wreg + row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4) + (g & 1) * 8) = pk;
+                *reinterpret_cast<u32x2*>(wreg + row * (CH * 16) + (epi_swz<CH>(chunk, row) << 4) + (g & 1) * 8) = pk;
             });
         });
         finish(std::integral_constant<int, CH>{}, (nt_base >> 1) * 16, e.N / 2);
@@ -314,7 +322,7 @@ __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[
                 pk.x = pack2bf(v[0], v[1]);
                 pk.y = pack2bf(v[2], v[3]);
                 const int chunk = 2 * t + (g >> 1);
-                *reinterpret_cast<u32x2*>(wreg + row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4) + (g & 1) * 8) = pk;
+                *reinterpret_cast<u32x2*>(wreg + row * (CH * 16) + (epi_swz<CH>(chunk, row) << 4) + (g & 1) * 8) = pk;
             });
         });
         finish(std::integral_constant<int, CH>{}, nt_base * 16, e.N);
