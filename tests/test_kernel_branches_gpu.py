@@ -91,7 +91,7 @@ TILED = [
     (8208, 3584, 18944, "residual", 266),     # down_proj + residual
     (8208, 37888, 3584, "swiglu", 266),       # gate/up SwiGLU
     (8192, 3456, 1152, "bias", 266),          # ViT fused q/k/v
-    (8192, 4304, 1152, "gelu", 266),          # ViT fc1 + GELU-tanh
+    (8192, 4304, 1152, "gelu", 384),          # ViT fc1 + GELU-tanh: 12 x 384 columns (the last block ragged)
     (8192, 1152, 4304, "residual", 384),      # ViT fc2 (+ residual): 3 x 384 columns, no padding
     (8192, 1152, 1152, "residual", 384),      # ViT out-proj
     (2064, 4608, 3584, "bias", 384),          # flow-pass QKV: 12 x 384 columns by 17 row blocks

@@ -1090,11 +1090,12 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
     const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long wg258 = (long)((M + 127) / 128) * ((N + 255) / 256);
     if (K < 1024) return 64;              // short K: the 4-buffer prologue does not amortise
-    if (wg256 >= 144 && N % 384 == 0) {
+    if (wg256 >= 144 && N <= 8192) {      // (wide N: many n-blocks either way, 256 x 256 wins or ties - 2064 x 37888: 602 vs 606 us)
         // N = 1152 (SigLIP out / fc2) is 4.5 tiles of 256: 10 % padding and 160 tiles for 256 CUs.  As 3 x 384 columns by 128 rows
-        // it is 192 tiles of 3/4 the work: rounds x tile area decides (out 46.7 -> 37.3 us, fc2 103.8 -> 89.9; the fused q/k/v
-        // GEMM, N = 3456, stays on 256 x 256: 76 vs 95 us)
-        const long cus = 256, t384 = (long)((M + 127) / 128) * (N / 384);
+        // it is 192 tiles of 3/4 the work: rounds x tile area decides (out 46.7 -> 37.3 us, fc2 103.8 -> 89.9, fc1 (N = 4304: 544
+        // tiles = 2.1 rounds against 768 = 3 rounds of 3/4) 120.3 -> 111.7; the fused q/k/v GEMM, N = 3456, stays on
+        // 256 x 256: 76 vs 95 us)
+        const long cus = 256, t384 = (long)((M + 127) / 128) * ((N + 383) / 384);
         const long c266 = (wg256 + cus - 1) / cus * 65536, c384 = (t384 + cus - 1) / cus * 49152;
         if (c384 * 10 < c266 * 9) return 384;
     }
