@@ -167,6 +167,54 @@ int umv_repack_weight_decode(const void* packed16, const float* scale16, void* o
 /* a->wp = decode image (a->w_scale = its scales when fp8); a->tile_rows is ignored; a->norm_w needs K <= 4096 */
 int umv_gemm_decode(const umv_gemm_args* a, const umv_decode_layout* L, int fp8, umv_stream_t stream);
 
+/* ------------------------------------------------------------------ decode layer engine (M <= 16): a CHAIN of the
+ * weight-streaming linears of one decode step as ONE persistent launch - the token loop of Bagel.generate_text
+ * (bagel.py:1262-1314) through Qwen2MoTDecoderLayer.forward_inference (qwen2_navit.py:843-902): o_proj + residual
+ * (:617-620,873-874), post_attention_layernorm (:876), mlp gate/up/SwiGLU/down (modeling_qwen2.py:234-235), residual
+ * (:897-898), the next layer's input_layernorm (:862) and q/k/v_proj (:541-543).  One workgroup per CU keeps the weight
+ * stream of op n+1 in flight (LDS-DMA ring, 14 KiB per wave) while op n's results travel between the workgroups through
+ * global memory (write-through stores + arrival counters + one agent-scope acquire per consumer); results equal
+ * umv_gemm_bf16 at M <= 16 (same K slices per wave, same summation order, same bf16 rounding points) followed by
+ * umv_residual_rmsnorm_bf16 / umv_rmsnorm_bf16 up to the order of the fp32 row sums of squares.
+ * Ops run in array order; `ops` lives in DEVICE memory (it is read with scalar loads by every workgroup). */
+enum { UMV_DE_GEMM = 0, UMV_DE_REDUCE = 1 };
+enum { UMV_DE_EPI_BF16 = 0, UMV_DE_EPI_RESIDUAL = 1, UMV_DE_EPI_PARTIAL = 2 };
+enum { UMV_DE_SIG_XCD = 0, UMV_DE_SIG_UNIT_DIV = 1, UMV_DE_SIG_GROUP_END = 2 };
+typedef struct {
+    const uint16_t* w;       /* GEMM: packed weight image (umv_pack_weight_bf16 / umv_pack_weight_swiglu_bf16) */
+    const uint16_t* x;       /* GEMM: input rows bf16 [M, ldx]; REDUCE: fp32 partial sums [kgroups][M][ldx] (as float*) */
+    int64_t ldx;
+    const uint16_t* norm_w;  /* GEMM, optional: x = Qwen2RMSNorm(x rows) * norm_w on the way in (K = KT*32, all of K) */
+    float norm_eps;
+    int32_t kind;            /* UMV_DE_GEMM / UMV_DE_REDUCE */
+    const uint16_t* bias;    /* GEMM, optional [N] */
+    uint16_t* resid;         /* EPI_RESIDUAL: residual rows (read); REDUCE: residual stream, updated in place */
+    int64_t ldr;
+    void* out;               /* bf16 [M, ldo]; EPI_PARTIAL: fp32 [kgroups][M][ldo] with split_stride floats between groups */
+    int64_t ldo;
+    int64_t split_stride;
+    const uint32_t* wait_cnt;/* optional: counter words (stride 16 words) that must reach wait_target before x is read */
+    uint32_t* sig_cnt;       /* optional: counter words bumped when a finished unit's stores are visible */
+    uint32_t wait_target;
+    int32_t wait_mode;       /* 0: sum of the 8 XCD shard words; 1: the word of this workgroup's K group */
+    int32_t sig_mode;        /* UMV_DE_SIG_*: word = XCD shard / unit index / sig_div / n-group (once, after the last unit) */
+    int32_t sig_div;
+    int32_t KT;              /* K / 32 */
+    int32_t ntiles;          /* 16-column tiles of the image (a SwiGLU pair counts 2); REDUCE: 16-column tiles of the row */
+    int32_t pair;            /* 1: (gate, up) tile pairs, SwiGLU epilogue, out = [M, ntiles/2*16] */
+    int32_t kgroups;         /* 1, or G % kgroups == 0: workgroup cu takes K group cu % kgroups of n-group cu / kgroups */
+    int32_t rot;             /* rotation of the n-group -> unit-range map (balances ops whose unit count is not a multiple) */
+    int32_t epi;             /* UMV_DE_EPI_* */
+    int32_t publish;         /* 1: the outputs are read by other workgroups of THIS launch (write-through stores) */
+    int32_t reserved;
+} umv_de_op;
+size_t umv_decode_engine_counter_words(void);
+/* counters: `counter_words` words zeroed on `stream` ahead of the launch (may be NULL when no op waits or signals);
+ * err: one word, non-zero after a bounded wait timed out (0xDE00xxxx); dummy_kib: any 1 KiB of readable device memory;
+ * grid: workgroups = CUs (256 on MI355X), a multiple of 8 - every workgroup must be resident. */
+int umv_decode_engine(const umv_de_op* ops_dev, int nops, int M, uint32_t* counters, size_t counter_words, uint32_t* err,
+                      const uint16_t* dummy_kib, int grid, umv_stream_t stream);
+
 /* ------------------------------------------------------------------ norms / elementwise */
 /* Qwen2RMSNorm (modeling_qwen2.py:89-94): out = w * bf16(x * rsqrt(mean(x^2)+eps)).
  * expert (optional, [T] int32): rows with expert[t]!=0 use w_gen (MoT *_moe_gen norms,

@@ -19,6 +19,7 @@ PAIRS = {   # C struct -> ctypes class name in unimedvl_amd._lib
     "umv_attn_decode_args": "AttnDecodeArgs",
     "umv_gemm8_args": "Gemm8Args",
     "umv_decode_layout": "DecodeLayout",
+    "umv_de_op": "DeOp",
 }
 
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libunimedvl_hip.so")
-SOURCES = ["elementwise.hip", "gemm.hip", "gemm_decode.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "attention_decode.hip", "vision.hip"]
+SOURCES = ["elementwise.hip", "gemm.hip", "gemm_decode.hip", "decode_engine.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "attention_decode.hip", "vision.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 # per-file additions.  attention_prefill: MFMA destinations stay in VGPRs (the compiler's default parks the 64 O accumulators in
