@@ -175,7 +175,7 @@ int umv_gemm_decode(const umv_gemm_args* a, const umv_decode_layout* L, int fp8,
  * stream of op n+1 in flight (LDS-DMA ring, 14 KiB per wave) while op n's results travel between the workgroups through
  * global memory (write-through stores + arrival counters + one agent-scope acquire per consumer); results equal
  * umv_gemm_bf16 at M <= 16 (same K slices per wave, same summation order, same bf16 rounding points) followed by
- * umv_residual_rmsnorm_bf16 / umv_rmsnorm_bf16 up to the order of the fp32 row sums of squares.
+ * umv_residual_rmsnorm_bf16 / umv_rmsnorm_bf16 up to the order of the fp32 row sums of squares.  M <= 8 rows.
  * Ops run in array order; `ops` lives in DEVICE memory (it is read with scalar loads by every workgroup). */
 enum { UMV_DE_GEMM = 0, UMV_DE_REDUCE = 1 };
 enum { UMV_DE_EPI_BF16 = 0, UMV_DE_EPI_RESIDUAL = 1, UMV_DE_EPI_PARTIAL = 2 };
@@ -195,6 +195,10 @@ typedef struct {
     int64_t split_stride;
     const uint32_t* wait_cnt;/* optional: counter words (stride 16 words) that must reach wait_target before x is read */
     uint32_t* sig_cnt;       /* optional: counter words bumped when a finished unit's stores are visible */
+    float* ss_out;           /* optional [ntiles][8]: per-row sums of squares of the FINAL bf16 values of each finished 16-column
+                                tile (EPI_RESIDUAL / REDUCE): the statistics of the RMSNorm the next op applies on the way in */
+    const float* ss_in;      /* norm_w set: the producers' ss_out, summed over ss_n tiles in a fixed order (NULL: the rows are
+                                squared here - only possible when x was complete before the launch) */
     uint32_t wait_target;
     int32_t wait_mode;       /* 0: sum of the 8 XCD shard words; 1: the word of this workgroup's K group */
     int32_t sig_mode;        /* UMV_DE_SIG_*: word = XCD shard / unit index / sig_div / n-group (once, after the last unit) */
@@ -206,14 +210,18 @@ typedef struct {
     int32_t rot;             /* rotation of the n-group -> unit-range map (balances ops whose unit count is not a multiple) */
     int32_t epi;             /* UMV_DE_EPI_* */
     int32_t publish;         /* 1: the outputs are read by other workgroups of THIS launch (write-through stores) */
-    int32_t reserved;
+    int32_t ss_n;
 } umv_de_op;
 size_t umv_decode_engine_counter_words(void);
 /* counters: `counter_words` words zeroed on `stream` ahead of the launch (may be NULL when no op waits or signals);
- * err: one word, non-zero after a bounded wait timed out (0xDE00xxxx); dummy_kib: any 1 KiB of readable device memory;
+ * err: one word, non-zero after a bounded wait timed out (0xDE00xxxx); dummy_kib: 1 KiB of ZEROS in device memory;
  * grid: workgroups = CUs (256 on MI355X), a multiple of 8 - every workgroup must be resident. */
 int umv_decode_engine(const umv_de_op* ops_dev, int nops, int M, uint32_t* counters, size_t counter_words, uint32_t* err,
                       const uint16_t* dummy_kib, int grid, umv_stream_t stream);
+/* tuning only: trace (optional) = [grid][64] 64-bit s_memtime stamps of every workgroup's lead service wave: launch entry, then
+ * per GEMM op {entry, producers seen, x staged, last tile published}, per REDUCE op {entry, producers seen, published} */
+int umv_decode_engine_traced(const umv_de_op* ops_dev, int nops, int M, uint32_t* counters, size_t counter_words, uint32_t* err,
+                             const uint16_t* dummy_kib, int grid, unsigned long long* trace, umv_stream_t stream);
 
 /* ------------------------------------------------------------------ norms / elementwise */
 /* Qwen2RMSNorm (modeling_qwen2.py:89-94): out = w * bf16(x * rsqrt(mean(x^2)+eps)).

@@ -79,15 +79,17 @@ class DeOp(C.Structure):
         ("w", C.c_void_p), ("x", C.c_void_p), ("ldx", C.c_int64), ("norm_w", C.c_void_p), ("norm_eps", C.c_float),
         ("kind", C.c_int32), ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64), ("out", C.c_void_p),
         ("ldo", C.c_int64), ("split_stride", C.c_int64), ("wait_cnt", C.c_void_p), ("sig_cnt", C.c_void_p),
-        ("wait_target", C.c_uint32), ("wait_mode", C.c_int32), ("sig_mode", C.c_int32), ("sig_div", C.c_int32),
+        ("ss_out", C.c_void_p), ("ss_in", C.c_void_p), ("wait_target", C.c_uint32), ("wait_mode", C.c_int32), ("sig_mode", C.c_int32), ("sig_div", C.c_int32),
         ("KT", C.c_int32), ("ntiles", C.c_int32), ("pair", C.c_int32), ("kgroups", C.c_int32), ("rot", C.c_int32),
-        ("epi", C.c_int32), ("publish", C.c_int32), ("reserved", C.c_int32),
+        ("epi", C.c_int32), ("publish", C.c_int32), ("ss_n", C.c_int32),
     ]
 
 
 _SIGS = {
     "umv_decode_engine_counter_words": (C.c_size_t, []),
     "umv_decode_engine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "umv_decode_engine_traced": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
     "umv_packed_weight_fp8_mfma_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "umv_repack_weight_fp8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_quantize_act_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,

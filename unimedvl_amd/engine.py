@@ -44,7 +44,8 @@ class Counters:
 
 
 def gemm_op(lin, x, *, out, KT=None, norm_w=None, eps=1e-6, resid=None, epi=EPI_BF16, kgroups=1, rot=0, publish=False,
-            wait=None, wait_target=0, wait_mode=0, sig=None, sig_mode=SIG_XCD, sig_div=1, split_stride=0, use_bias=True):
+            wait=None, wait_target=0, wait_mode=0, sig=None, sig_mode=SIG_XCD, sig_div=1, split_stride=0, use_bias=True,
+            ss_out=None, ss_in=None, ss_n=0):
     """One GEMM op of a chain over the PackedLinear `lin` (16-row bf16 image)."""
     if lin.th != 16 or lin.wp is None:
         raise _lib.UmvError("decode engine: needs the standard bf16 weight image")
@@ -61,11 +62,12 @@ def gemm_op(lin, x, *, out, KT=None, norm_w=None, eps=1e-6, resid=None, epi=EPI_
     o.wait_cnt, o.wait_target, o.wait_mode = (wait or 0), wait_target, wait_mode
     o.sig_cnt, o.sig_mode, o.sig_div = (sig or 0), sig_mode, sig_div
     o.KT, o.ntiles, o.pair, o.kgroups, o.rot = KT, lin.N // 16, 1 if lin.swiglu else 0, kgroups, rot
-    o.epi, o.publish, o.reserved = epi, 1 if publish else 0, 0
+    o.epi, o.publish = epi, 1 if publish else 0
+    o.ss_out, o.ss_in, o.ss_n = _ptr(ss_out), _ptr(ss_in), ss_n
     return o
 
 
-def reduce_op(partials, seq, *, kgroups, wait=None, wait_target=0, sig=None, sig_div=1, publish=True):
+def reduce_op(partials, seq, *, kgroups, wait=None, wait_target=0, sig=None, sig_div=1, publish=True, ss_out=None):
     """seq[:, tile] = bf16(bf16(sum_g partials[g][:, tile]) + seq[:, tile]) - workgroup i finishes 16-column tile i."""
     o = DeOp()
     o.kind = DE_REDUCE
@@ -74,6 +76,7 @@ def reduce_op(partials, seq, *, kgroups, wait=None, wait_target=0, sig=None, sig
     o.wait_cnt, o.wait_target, o.wait_mode = (wait or 0), wait_target, 1
     o.sig_cnt, o.sig_mode, o.sig_div = (sig or 0), SIG_XCD, sig_div
     o.ntiles, o.kgroups, o.publish = seq.shape[1] // 16, kgroups, 1 if publish else 0
+    o.ss_out = _ptr(ss_out)
     return o
 
 
@@ -90,9 +93,14 @@ class EngineProgram:
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self.dummy = torch.zeros(512, dtype=BF16, device=device)
 
-    def launch(self):
+    def launch(self, trace=None):
         lib = _lib.load()
         cnt = self.counters.buf if self.counters is not None else None
+        if trace is not None:      # tuning only: [grid][64] int64 timeline of the lead service waves
+            check(lib.umv_decode_engine_traced(self.table.data_ptr(), self.n, self.M, _ptr(cnt), 0 if cnt is None else cnt.numel(),
+                                               self.err.data_ptr(), self.dummy.data_ptr(), self.grid, trace.data_ptr(), ops._stream()),
+                  "umv_decode_engine_traced")
+            return
         check(lib.umv_decode_engine(self.table.data_ptr(), self.n, self.M, _ptr(cnt), 0 if cnt is None else cnt.numel(),
                                     self.err.data_ptr(), self.dummy.data_ptr(), self.grid, ops._stream()), "umv_decode_engine")
 
@@ -102,7 +110,7 @@ class EngineProgram:
             raise _lib.UmvError(f"decode engine: a bounded wait timed out (code {e & 0xFFFFFFFF:#x}): results are invalid")
 
 
-def layer_chain(lw, nxt_norm, nxt_qkv, *, attn_out, seq, act, p_h, qkv_out, eps, device, counters, G=256, kgroups=8):
+def layer_chain(lw, nxt_norm, nxt_qkv, *, attn_out, seq, act, p_h, qkv_out, eps, device, counters, ss, G=256, kgroups=8):
     """The op list of one decoder layer after its attention: o_proj ... (next) q/k/v_proj.  `nxt_qkv` None = last layer:
     the chain ends with the residual stream complete in `seq` (the final norm + lm_head are the caller's)."""
     H = lw.o.N
@@ -115,16 +123,18 @@ def layer_chain(lw, nxt_norm, nxt_qkv, *, attn_out, seq, act, p_h, qkv_out, eps,
     pairs_per_kg = (I // 16) // kgroups
     assert (I // 16) % kgroups == 0 and (lw.down.K // 32) % kgroups == 0 and G % kgroups == 0
     assert (H // 16) % (G // kgroups) == 0
+    # ss [2][H/16][8] fp32: per-tile row sums of squares of the residual stream after o_proj / after down_proj
     chain = [
-        gemm_op(lw.o, attn_out, out=seq, resid=seq, epi=EPI_RESIDUAL, publish=True, sig=c_o, sig_mode=SIG_XCD),
+        gemm_op(lw.o, attn_out, out=seq, resid=seq, epi=EPI_RESIDUAL, publish=True, sig=c_o, sig_mode=SIG_XCD, ss_out=ss[0]),
         gemm_op(lw.gate_up, seq, out=act, norm_w=lw.post_norm, eps=eps, publish=True, wait=c_o, wait_target=n_o, wait_mode=0,
-                sig=c_gu, sig_mode=SIG_UNIT_DIV, sig_div=pairs_per_kg),
+                sig=c_gu, sig_mode=SIG_UNIT_DIV, sig_div=pairs_per_kg, ss_in=ss[0], ss_n=n_o),
         gemm_op(lw.down, act, out=p_h, epi=EPI_PARTIAL, kgroups=kgroups, publish=True, split_stride=p_h.stride(0),
                 wait=c_gu, wait_target=pairs_per_kg, wait_mode=1, sig=c_dn, sig_mode=SIG_GROUP_END),
-        reduce_op(p_h, seq, kgroups=kgroups, wait=c_dn, wait_target=kgroups, sig=c_rd, sig_div=(H // 16) // (G // kgroups)),
+        reduce_op(p_h, seq, kgroups=kgroups, wait=c_dn, wait_target=kgroups, sig=c_rd, sig_div=(H // 16) // (G // kgroups),
+                  ss_out=ss[1]),
     ]
     if nxt_qkv is not None:
         # 288 q/k/v tiles on 256 workgroups: the 32 workgroups that had no o_proj tile take the second one
         chain.append(gemm_op(nxt_qkv, seq, out=qkv_out, norm_w=nxt_norm, eps=eps, rot=(G - n_o) % G, wait=c_rd, wait_target=n_o,
-                             wait_mode=0))
+                             wait_mode=0, ss_in=ss[1], ss_n=n_o))
     return chain
