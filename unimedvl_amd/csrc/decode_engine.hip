@@ -34,16 +34,13 @@
 #define DE_SW 8                      // streaming waves
 #define DE_NSV 4                     // service waves
 #define DE_THREADS ((DE_SW + DE_NSV) * 64)
-#define DE_R 10                      // ring pieces (KiB) per streaming wave
-#define DE_NB 2                      // pieces per batch of the consuming loop (DE_XK % DE_NB == 0)
-#define DE_XK 14                     // k-tiles of x a wave keeps in registers (its K slice)
+#define DE_XK 14                     // k-tiles per wave slice and tile = pieces per register frame
 #define DE_MROWS 8                   // rows (tokens) per step
-#define DE_RING_BYTES (DE_SW * DE_R * 1024)
 #define DE_RED_BYTES (2 * DE_SW * 2 * 32 * 16)              // [buf][wave][part][g*8 + r] f32x4
 #define DE_XS_BYTES (DE_SW * DE_XK * 4 * DE_MROWS * 16)     // [wave][kk][g][r] 16-byte fragment pieces of x
 #define DE_NW_BYTES (DE_SW * DE_XK * 4 * 16)                // [k-tile][g] norm weights
 #define DE_MISC_BYTES 256
-#define DE_LDS_BYTES (DE_RING_BYTES + DE_RED_BYTES + DE_XS_BYTES + DE_NW_BYTES + DE_MISC_BYTES)
+#define DE_LDS_BYTES (DE_RED_BYTES + DE_XS_BYTES + DE_NW_BYTES + DE_MISC_BYTES)
 #define DE_SPIN_LIMIT 400000u
 #define DE_MAXKG 8                   // K groups of a partial-sum op
 #define DE_SS_PER_LANE 28             // ss_in tiles per lane of the service wave (8 * 28 = 224 tiles = 3584 columns)
@@ -102,31 +99,36 @@ __device__ __forceinline__ int de_slice_nk(const DeShare& s, int wave) {
     return ke - kb;
 }
 
-// the weight stream of a streaming wave: runs DE_R pieces ahead of the consumer, across tiles and ops
-struct DeProd {
-    int op, t, t1, kk, nk;
+// the tile runs of a workgroup: GEMM ops with work, tile by tile.  Two cursors walk them: the consumer, and the loader two runs ahead.
+struct DeIter {
+    int op, t, t1, nk;
     int64_t tstride;            // bytes between consecutive tiles of the image
-    const char* lane_base;      // image + (first k-tile of the slice * 64 + lane) * 16
+    const char* lane_base;      // image + (first k-tile of this wave's slice * 64 + lane) * 16
 };
 
-__device__ __forceinline__ void de_prod_seek(DeProd& P, de_ops_t ops, int nops, int cu, int G, int wave, int lane) {
-    while (P.op < nops) {
-        const auto& o = ops[P.op];
+__device__ __forceinline__ void de_iter_seek(DeIter& it, de_ops_t ops, int nops, int cu, int G, int wave, int lane) {
+    while (it.op < nops) {
+        const auto& o = ops[it.op];
         if (o.kind == UMV_DE_GEMM) {
             const DeShare s = de_share(o, cu, G);
-            const int nk = de_slice_nk(s, wave);
-            if (s.t0 < s.t1 && nk > 0) {
-                P.t = s.t0; P.t1 = s.t1; P.kk = 0; P.nk = nk;
-                P.tstride = (int64_t)o.KT * 1024;
-                P.lane_base = reinterpret_cast<const char*>(o.w) + ((int64_t)(s.kbase + wave * s.kt_per) * 64 + lane) * 16;
+            if (s.t0 < s.t1) {
+                it.t = s.t0; it.t1 = s.t1; it.nk = de_slice_nk(s, wave);
+                it.tstride = (int64_t)o.KT * 1024;
+                it.lane_base = reinterpret_cast<const char*>(o.w) + ((int64_t)(s.kbase + wave * s.kt_per) * 64 + lane) * 16;
                 return;
             }
         }
-        ++P.op;
+        ++it.op;
+    }
+}
+__device__ __forceinline__ void de_iter_next(DeIter& it, de_ops_t ops, int nops, int cu, int G, int wave, int lane) {
+    if (++it.t == it.t1) {
+        ++it.op;
+        de_iter_seek(it, ops, nops, cu, G, wave, lane);
     }
 }
 
-// DBG (tuning only): 1 = no LDS fragment read / MFMA, 4 = default cache policy instead of non-temporal weight loads
+// DBG (tuning only): 1 = no MFMA, 8 = no x copy, 16 = no row squaring in the fallback path
 template <int DBG>
 __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_op* __restrict__ ops_g, int nops, int M, int G,
                                                                    uint32_t* __restrict__ err, const uint16_t* __restrict__ zeros,
@@ -137,118 +139,83 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cu = blockIdx.x;
-    f32x4* red = reinterpret_cast<f32x4*>(smem + DE_RING_BYTES);
-    char* xs = smem + DE_RING_BYTES + DE_RED_BYTES;
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    char* xs = smem + DE_RED_BYTES;
     char* nws = xs + DE_XS_BYTES;
     float* misc = reinterpret_cast<float*>(nws + DE_NW_BYTES);   // [0..7] rstd per row
 
     if (wave < DE_SW) {
         // =========================================================================== streaming wave
+        // The weight stream lives in REGISTERS: two frames of 14 pieces (16 bytes per lane each = one 16 x 32 tile of the image as
+        // an MFMA A fragment), frame A = the run being consumed, frame B = the next one; a piece's registers are reloaded - for
+        // the run after next - right behind the MFMA that consumed them, so 28 KiB per wave (224 KiB per CU, ~9 us of stream)
+        // stay in flight across tile, op and dependency boundaries.  Plain non-temporal loads: the compiler counts vmcnt; these
+        // are the only vector-memory operations of a streaming wave.  Unused positions (a slice shorter than 14 k-tiles, the end of
+        // the program) load the zero page, so the queue depth never changes.
         const int r = lane & 15, g = lane >> 4;
-        char* ring = smem + wave * (DE_R * 1024);
-        DeProd P;
-        P.op = 0; P.t = P.t1 = P.kk = P.nk = 0; P.tstride = 0; P.lane_base = nullptr;
-        de_prod_seek(P, ops, nops, cu, G, wave, lane);
         const char* zero_lane = reinterpret_cast<const char*>(zeros) + lane * 16;
-        auto issue = [&](int slot) {
-            const char* src;
-            if (P.op < nops) {
-                src = P.lane_base + ((int64_t)P.t * P.tstride + (int64_t)P.kk * 1024);
-                if (++P.kk == P.nk) {
-                    P.kk = 0;
-                    if (++P.t == P.t1) {
-                        ++P.op;
-                        de_prod_seek(P, ops, nops, cu, G, wave, lane);
-                    }
-                }
-            } else {
-                src = zero_lane;       // keep DE_R pieces in flight to the end: every counted wait sees the same queue depth
-            }
-            if constexpr (DBG & 4) __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(ring + slot * 1024), 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(ring + slot * 1024), 16, 0, 2 /* nt */);
+        DeIter C, P;
+        C.op = 0; C.t = C.t1 = C.nk = 0; C.tstride = 0; C.lane_base = nullptr;
+        de_iter_seek(C, ops, nops, cu, G, wave, lane);
+        P = C;
+        bf16x8 FA[DE_XK], FB[DE_XK];
+        auto fill = [&](bf16x8(&F)[DE_XK]) {       // the run under the loader cursor -> F, cursor to the next run
+            const bool pv = P.op < nops;
+            const char* base = pv ? P.lane_base + (int64_t)P.t * P.tstride : zero_lane;
+            const int pnk = pv ? P.nk : 0;
+#pragma unroll
+            for (int kk = 0; kk < DE_XK; ++kk)
+                F[kk] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kk < pnk ? base + kk * 1024 : zero_lane));
+            if (pv) de_iter_next(P, ops, nops, cu, G, wave, lane);
         };
-#pragma unroll 1
-        for (int s = 0; s < DE_R; ++s) issue(s);
-        int slot = 0;
+        fill(FA);
+        fill(FB);
+        const bool rowok = r < DE_MROWS;
+        const char* xlane = xs + ((wave * DE_XK * 4 + g) * DE_MROWS + (rowok ? r : 0)) * 16;
         int unit_no = 0;      // tiles finished by this workgroup: red double buffer
+        int cur_op = -1;
+        int pair = 0, t0 = 0;
 
-        for (int oi = 0; oi < nops; ++oi) {
-            const auto& op = ops[oi];
-            if (op.kind != UMV_DE_GEMM) continue;
-            const DeShare S = de_share(op, cu, G);
-            if (S.t0 >= S.t1) continue;                   // workgroup-uniform: the service wave skips the same barriers
-            const int nk = de_slice_nk(S, wave);
-            if (op.wait_cnt) __builtin_amdgcn_s_barrier();                          // B0: the lead service wave saw the producers
-            if (op.norm_w && !op.ss_in) __builtin_amdgcn_s_barrier();                // (rows squared by the lead once every part is staged)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                 // B1: the service waves have staged x (and the norm weights / scale)
-
-            // ---- x slice of this wave -> registers (B-operand fragments); Qwen2RMSNorm on the way (two bf16 roundings)
-            bf16x8 x[DE_XK];
-            {
-                const bool rowok = r < DE_MROWS;
-                const char* xp = xs + ((wave * DE_XK * 4 + g) * DE_MROWS + (rowok ? r : 0)) * 16;
-#pragma unroll
-                for (int kk = 0; kk < DE_XK; ++kk)
-                    x[kk] = (kk < nk && rowok) ? *reinterpret_cast<const bf16x8*>(xp + kk * (4 * DE_MROWS * 16)) : zero_frag();
-                if (op.norm_w) {
-                    const float rstd = misc[rowok ? r : 0];
-                    const char* wp = nws + ((wave * S.kt_per) * 4 + g) * 16;
-#pragma unroll
-                    for (int kk = 0; kk < DE_XK; ++kk) {
-                        const bf16x8 nw = *reinterpret_cast<const bf16x8*>(wp + kk * 64);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            x[kk][j] = (short)f2bf(bf2f((bf16_t)nw[j]) * rbf(bf2f((bf16_t)x[kk][j]) * rstd));
-                    }
-                }
+        auto run = [&](bf16x8(&F)[DE_XK]) {
+            if (C.op != cur_op) {                 // op entry: wait until the service waves have staged (and normalised) x
+                cur_op = C.op;
+                const auto& op = ops[cur_op];
+                pair = op.pair;
+                t0 = C.t;
+                if (op.wait_cnt) __builtin_amdgcn_s_barrier();                          // B0: the lead service wave saw the producers
+                if (op.norm_w) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // raw x staged; scale known
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                                           // B1: x is ready in LDS
             }
-
-            const int mul = op.pair ? 2 : 1;
-            for (int t = S.t0; t < S.t1; t += mul) {
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                for (int part = 0; part < mul; ++part) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const bool pv = P.op < nops;
+            const char* base = pv ? P.lane_base + (int64_t)P.t * P.tstride : zero_lane;
+            const int pnk = pv ? P.nk : 0;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kb = 0; kb < DE_XK; kb += DE_NB) {
-                        if (kb < nk) {
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DE_R - DE_NB) : "memory");    // the DE_NB oldest pieces have landed
-                            bf16x8 wf[DE_NB];
-                            if constexpr (!(DBG & 1)) {
-#pragma unroll
-                                for (int j = 0; j < DE_NB; ++j) {
-                                    const int sl = slot + j >= DE_R ? slot + j - DE_R : slot + j;
-                                    wf[j] = *reinterpret_cast<const bf16x8*>(ring + sl * 1024 + lane * 16);
-                                }
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and have been read: refill their slots
-                            }
-#pragma unroll
-                            for (int j = 0; j < DE_NB; ++j)
-                                if (kb + j < nk) {
-                                    issue(slot);
-                                    slot = slot + 1 == DE_R ? 0 : slot + 1;
-                                }
-#pragma unroll
-                            for (int j = 0; j < DE_NB; ++j) {
-                                if constexpr (!(DBG & 1)) { if (kb + j < nk) a = mfma16(wf[j], x[kb + j], a); }
-                                else asm volatile("" : "+v"(a));
-                            }
-                        }
-                    }
-                    if (part == 0) acc0 = a; else acc1 = a;
-                }
-                // ---- the 8 K slices meet in LDS (rows < 8 only); the service wave finishes the tile in wave order
-                if (r < DE_MROWS) {
-                    f32x4* rb = red + (((unit_no & 1) * DE_SW + wave) * 2) * 32 + g * 8 + r;
-                    rb[0] = acc0;
-                    if (mul == 2) rb[32] = acc1;
-                }
+            for (int kk = 0; kk < DE_XK; ++kk) {
+                const bf16x8 xf = rowok ? *reinterpret_cast<const bf16x8*>(xlane + kk * (4 * DE_MROWS * 16)) : zero_frag();
+                if constexpr (!(DBG & 1)) { if (kk < C.nk) a = mfma16(F[kk], xf, a); }
+                else asm volatile("" : "+v"(a) : "v"(F[kk]), "v"(xf));
+                F[kk] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kk < pnk ? base + kk * 1024 : zero_lane));
+            }
+            if (pv) de_iter_next(P, ops, nops, cu, G, wave, lane);
+            // ---- the 8 K slices meet in LDS (rows < 8 only); the lead service wave finishes the tile in wave order
+            const int part = pair ? ((C.t - t0) & 1) : 0;
+            if (rowok) red[(((unit_no & 1) * DE_SW + wave) * 2 + part) * 32 + g * 8 + r] = a;
+            if (!pair || part) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 ++unit_no;
             }
+            de_iter_next(C, ops, nops, cu, G, wave, lane);
+        };
+        while (C.op < nops) {
+            run(FA);
+            if (C.op >= nops) break;
+            run(FB);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup's LDS allocation
+#pragma unroll
+        for (int kk = 0; kk < DE_XK; ++kk) asm volatile("" ::"v"(FA[kk]), "v"(FB[kk]));   // (the trailing zero-page loads stay counted)
         return;
     }
 
@@ -393,29 +360,46 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
                 else __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(xs + i * 1024), 16, 0, 0);
             }
         }
-        if (op.norm_w && !op.ss_in) {      // x was complete before the launch: square the staged rows (every service wave stages a part)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (sv == 0 && !(DBG & 16)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (op.norm_w) {
+            __builtin_amdgcn_s_barrier();                   // raw x and the norm weights are in LDS (every service wave copied a part)
+            if (sv == 0) {
+                if (!op.ss_in && !(DBG & 16)) {             // x was complete before the launch: square the staged rows
 #pragma unroll 8
-                for (int q = c8; q < DE_SW * DE_XK * 4; q += 8) {
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + (q * DE_MROWS + r8) * 16);
+                    for (int q = c8; q < DE_SW * DE_XK * 4; q += 8) {
+                        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + (q * DE_MROWS + r8) * 16);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float f = bf2f((bf16_t)v[j]);
-                        ss += f * f;
+                        for (int j = 0; j < 8; ++j) {
+                            const float f = bf2f((bf16_t)v[j]);
+                            ss += f * f;
+                        }
                     }
                 }
+                ss += __shfl_xor(ss, 8, 64);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                if (lane < DE_MROWS) misc[lane] = rsqrt_ieee(ss / (float)(op.KT * 32) + op.norm_eps);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // the scale of every row is known
+            // Qwen2RMSNorm in place, two bf16 roundings (modeling_qwen2.py:89-94): x <- bf16(w * bf16(x * rstd)); 16-byte slot
+            // u = ((slice*14 + kk)*4 + g)*8 + row, a quarter of the slots per service wave
+            const float rstd = misc[r8];
+#pragma unroll 2
+            for (int it = 0; it < DE_SW * DE_XK * 4 * DE_MROWS / (64 * DE_NSV); ++it) {
+                const int u = (sv * (DE_SW * DE_XK * 4 * DE_MROWS / (64 * DE_NSV)) + it) * 64 + lane;
+                const int chunk = u >> 3;
+                const int w = chunk / (DE_XK * 4), rem = chunk - w * (DE_XK * 4);
+                const int kk = rem >> 2, gq = rem & 3;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + u * 16);
+                const bf16x8 nw = *reinterpret_cast<const bf16x8*>(nws + ((w * S.kt_per + kk) * 4 + gq) * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)nw[j]) * rbf(bf2f((bf16_t)v[j]) * rstd));
+                *reinterpret_cast<bf16x8*>(xs + u * 16) = v;
             }
         }
-        if (sv == 0 && op.norm_w) {
-            ss += __shfl_xor(ss, 8, 64);
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            if (lane < DE_MROWS) misc[lane] = rsqrt_ieee(ss / (float)(op.KT * 32) + op.norm_eps);
-        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // B1: x (+ norm weights, scales) are in LDS
+        __builtin_amdgcn_s_barrier();                       // B1: x is ready in LDS
         stamp();
 
         // (e) finish the tiles as the streaming waves deliver them (the lead; the others only keep the barrier count)
