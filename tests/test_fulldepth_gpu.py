@@ -100,10 +100,16 @@ def test_full_depth_vqa_single_request(fd):
     for l, mk, fk, mv, fv in rows:
         if l in (0, 1, 6, 13, 20, 27):
             print(f"  layer {l:2d}: K {mk:.4f} / {fk:.4f}   V {mv:.4f} / {fv:.4f}")
-XX
+    # Measured on MI355X (round 3): max error 0.013 of range at layer 0, 0.031 at layer 13, 0.038 at layer 27; relative
+    # Frobenius error 0.009 -> 0.024 -> 0.033: the deviation grows roughly with the square root of the depth.  Bounds: SURVEY 8c's
+    # 2e-2 of range for the first two layers, 2x the measured worst case (0.08 / 0.065) below them.
+    for l, mk, fk, mv, fv in rows:
+        lim_max = 0.02 if l < 2 else 0.08
+        assert mk <= lim_max and mv <= lim_max, f"layer {l}: K / V max error {mk:.4f} / {mv:.4f} of range (bound {lim_max})"
+        assert fk <= 0.065 and fv <= 0.065, f"layer {l}: K / V relative Frobenius error {fk:.4f} / {fv:.4f} (bound 0.065)"
 
     # ---- teacher-forced greedy decode under the HIP graph: the oracle is fed the engine's input token of every step
-    steps = 4
+    steps = 8
     gs = model.prepare_start_tokens(kvl, rope, ntid)
     sess = DecodeSession(model.language_model, cache, gs["packed_start_tokens"], gs["packed_query_position_ids"], steps + 1, use_graph=True)
     assert sess.graph is not None
@@ -125,9 +131,10 @@ XX
         assert int(lg.argmax(-1)[0]) == pred
         print(f"  step {s}: |logit diff| max {d:.4f} (logit range {ref.abs().max().item():.2f}), cosine {cos:.6f}, oracle top-2 margin "
               f"{margin:.3f}, ids {pred} / {ref_pred}")
-        assert d <= 0.5, f"step {s}: logits differ by {d} (bound 0.5 = 2x measured)"
-        assert cos > 0.995, f"step {s}: logits cosine {cos}"
-        if margin > 2 * 0.5:
+        # measured on MI355X (round 3): 0.148 - 0.164 on logits of range 5.3 - 5.7, cosine 0.99957 - 0.99962
+        assert d <= 0.33, f"step {s}: logits differ by {d} (bound 0.33 = 2x measured)"
+        assert cos > 0.999, f"step {s}: logits cosine {cos}"
+        if margin > 0.33:
             assert pred == ref_pred, f"step {s}: greedy id {pred} vs oracle {ref_pred} despite a top-2 margin of {margin:.3f}"
             exact += 1
         # the engine's choice is always within the deviation bound of the oracle's best logit
