@@ -226,6 +226,7 @@ def test_configs2_t2i_256_guided_flow_and_pixels(fw):
     # which is all its inferencer ever uses)
     n_tok = (hw // cfg.latent_downsample) ** 2
     worst = 0.0
+    pix_stats, lat_devs = [], []
     for b in range(B):
         ob = KVCache(cfg.layers, 1)
         for l in range(cfg.layers):
@@ -238,16 +239,28 @@ def test_configs2_t2i_256_guided_flow_and_pixels(fw):
         for i, (x, ox) in enumerate(zip(trace, otrace)):
             d = (x[b * n_tok:(b + 1) * n_tok].cpu() - ox).abs()
             worst = max(worst, d.max().item())
-            assert d.max().item() < 0.15 and d.mean().item() < 0.02, f"sample {b} step {i}: latent max {d.max().item()} mean {d.mean().item()}"
+            lat_devs.append(d.flatten())
+            # measured (MI355X, round 3): max 0.0625, mean 0.0056, p99 0.030 -> bounds at 2x
+            assert d.max().item() <= 0.125 and d.mean().item() < 0.012, f"sample {b} step {i}: latent max {d.max().item()} mean {d.mean().item()}"
         if b < 2:       # full-size VAE decoder + truncating uint8 (inferencer.py:234-256) on the ORACLE's latent for both
             px = vae.decode_tokens_to_uint8(olat[0], (hw, hw), model.latent_downsample, model.latent_patch_size).cpu()
             ref = oracle.decode_image(olat[0], (hw, hw))
             assert px.shape == ref.shape == (hw, hw, 3)
             diff = (px.int() - ref.int()).abs()
-            assert (diff <= 4).float().mean().item() >= 0.99 and diff.max().item() <= 24, \
-                f"pixels sample {b}: {100 * (diff <= 4).float().mean().item():.2f}% within 4 levels, max {diff.max().item()}"
+            dist = {k: round(100 * (diff <= k).float().mean().item(), 3) for k in (0, 1, 2, 4, 8)}
+            print(f"configs[2] pixels sample {b}: % of uint8 values within k grey levels {dist}, max {diff.max().item()}, "
+                  f"mean {diff.float().mean().item():.3f}")
+            pix_stats.append((dist, diff.max().item()))
+            # +-2 grey levels on >= 99 % of the values (the decoder is ~30 bf16 stages deep and the conversion
+            # truncates, so a 1-ulp difference upstream flips a grey level)
+            # measured (MI355X, round 3): 53-54 % exact, 92.3-92.5 % within 1, 99.71-99.72 % within 2, max 4-5 levels
+            assert dist[2] >= 99.0 and diff.max().item() <= 8, \
+                f"pixels sample {b}: {dist}, max {diff.max().item()}"
     assert gen.lens == cfg_img.lens == kvl and cfg_text.seq_lens == 0, "flow passes must not commit KV"
-    print(f"configs[2] B=4 256x256: worst latent deviation over {steps - 1} Euler steps {worst:.4f}")
+    allv = torch.cat(lat_devs)
+    q = torch.quantile(allv[torch.randperm(allv.numel())[:2_000_000]].float(), torch.tensor([0.5, 0.9, 0.99, 0.999]))
+    print(f"configs[2] B=4 256x256: latent deviation over {steps - 1} Euler steps: max {worst:.4f} (bound 0.125), mean {allv.mean().item():.5f} "
+          f"(bound 0.012), p50 / p90 / p99 / p99.9 = {q[0]:.4f} / {q[1]:.4f} / {q[2]:.4f} / {q[3]:.4f}")
 
 
 @pytest.mark.parametrize("act8", [False, True])
@@ -296,5 +309,149 @@ def test_configs4_fp8_weights_fullwidth(fw, act8):
         print(f"W8A8 full width: last-layer keys rel fro {rel:.4f}")
         assert rel <= 0.08, f"W8A8 last-layer keys: relative Frobenius error {rel}"       # measured 0.058 (tiny model: 0.04)
         _forced_decode_check(m8, o8, cache, oc, kvl, rope, ntid, 12, "configs[4] W8A8 B=4")   # measured worst 0.0625
+    del m8
+    torch.cuda.empty_cache()
+
+
+def test_edit_path_448_vae_encode_and_gen_prefill(fw):
+    """The image-editing input path at FULL size (VERDICT r02 "next" #3c): AutoEncoder.encode of a 448 x 448 image
+    (autoencoder.py:300-303: 829 GFLOP of convolutions, 128 -> 512 channels, the mid-block attention over 3136 positions at
+    hd 512), the sample z = mean + std * noise with injected noise, vae2llm + timestep-0 embedding + latent position table
+    (bagel.py:757-790) and the gen-mode (MoT, non-causal) prefill of the 786-token span through both experts
+    (bagel.py:697-806, qwen2_navit.py:552-562,891-898) - against the CPU oracle on the same weights, image and noise."""
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    model, vae, oracle, cfg, ntid = fw
+    img = _synth_image(448, 448, 555)
+    g = torch.Generator().manual_seed(556)
+    noise = torch.randn(1, cfg.z_channels, 448 // 8, 448 // 8, generator=g).to(BF16)
+    # ---- the VAE encoder alone (the latent the LLM is fed)
+    lat = vae.encode(img[None], noise=noise).float().cpu()
+    ref = oracle.vae_encode(img[None].to(BF16), noise).float()
+    assert lat.shape == ref.shape == (1, cfg.z_channels, 56, 56)
+    d = (lat - ref).abs()
+    q = torch.quantile(d.flatten(), torch.tensor([0.5, 0.99]))
+    print(f"edit path 448x448: VAE latent |diff| max {d.max().item():.4f} mean {d.mean().item():.5f} p50 {q[0]:.4f} p99 {q[1]:.4f} "
+          f"(latent range {ref.abs().max().item():.2f})")
+    assert d.max().item() <= 0.03 * ref.abs().max().item() and d.mean().item() <= 0.004 * ref.abs().max().item(), \
+        f"VAE encode: max {d.max().item()} mean {d.mean().item()} vs range {ref.abs().max().item()}"
+    # ---- the whole gen-mode prefill
+    cache = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_vae_images([0], [0], [img], lambda x: x, ntid)
+    cache = model.forward_cache_update_vae(vae, cache, noise=noise, **gi)
+    oc = KVCache(cfg.layers, 1)
+    okv, orope = oracle.update_vae(oc, [0], [0], [img], ntid, noise=noise)
+    assert okv == kvl == [28 * 28 + 2] and orope == rope
+    _check_kv(cache, oc, range(cfg.layers), 2e-2, "edit path, gen-mode prefill of the 786-token span")
+
+
+def test_configs4_mixed_fullwidth(fw):
+    """configs[4] as written: e4m3 weights + e4m3 activations (W8A8), VQA requests and text-to-image requests IN ONE STEP
+    STREAM (serving.MixedBatcher) at the full widths: 4 VQA slots (448 x 448 image + 32-token question) decode while a
+    group of two 256 x 256 images goes through its guided flow passes on the fp8 matrix instruction and the full-size VAE.
+    PARITY UNPINNED BY THE REFERENCE (no fp8 path there): the checker is OracleBagel(act_fp8=True) on the dequantised
+    weights (oracle/fp8.py).  Checked: (1) the mixed run reproduces each request served alone bit for bit (greedy ids /
+    final latents); (2) the W8A8 latents after every Euler step against the oracle, measured deviation printed next to the
+    bound; (3) uint8 pixels through the full-size VAE."""
+    from oracle import fp8
+    from oracle.unimedvl_cpu import KVCache, OracleBagel
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.kvcache import NaiveCache
+    from unimedvl_amd.serving import MixedBatcher
+    model, vae, oracle, cfg, ntid = fw
+    sd_cpu = oracle.sd
+    cfg8 = UniMedVLConfig.from_dict(cfg.to_dict())
+    cfg8.llm_weight_dtype, cfg8.llm_act_dtype = "fp8", "fp8"
+    m8 = Bagel(cfg8, lambda n: sd_cpu[n], device=model.device, visual_gen=True, visual_und=True)
+    if not hasattr(test_configs4_fp8_weights_fullwidth, "_deq"):
+        test_configs4_fp8_weights_fullwidth._deq = fp8.dequantised_weights(sd_cpu)
+    o8 = OracleBagel(cfg.to_dict(), test_configs4_fp8_weights_fullwidth._deq, oracle.vae_sd, attn_impl="flash", act_fp8=True)
+
+    class Tok(IdTok):                       # ids in, ids out: the answers are compared as token strings
+        def decode(self, ids):
+            return "<|im_start|>" + " ".join(str(int(v)) for v in ids[1:]) + "<|im_end|>"
+    nv, ni, hw, steps, new = 4, 2, 256, 5, 8
+    images = [_synth_image(448, 448, 700 + i) for i in range(nv)]
+    table = _prompts([32] * nv, 21) + _prompts([128] * ni, 22)
+    tok = Tok(table)
+    ident = lambda x: x   # noqa: E731
+    n_tok = (hw // cfg.latent_downsample) ** 2
+    g = torch.Generator().manual_seed(23)
+    noises = [torch.randn(n_tok, cfg.latent_patch ** 2 * cfg.z_channels, generator=g) for _ in range(ni)]
+    kw = dict(num_timesteps=steps, timestep_shift=3.0, cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0,
+              cfg_renorm_type="global")
+
+    # ---- every request served ALONE on the same engine
+    alone_ids = []
+    for i in range(nv):
+        c = NaiveCache(cfg.layers)
+        gi, kvl, rope = m8.prepare_vit_images([0], [0], [images[i]], ident, ntid)
+        c = m8.forward_cache_update_vit(c, **gi)
+        gi, kvl, rope = m8.prepare_prompts(kvl, rope, [str(i)], tok, ntid)
+        c = m8.forward_cache_update_text(c, **gi)
+        gs = m8.prepare_start_tokens(kvl, rope, ntid)
+        ids = m8.generate_text(past_key_values=c, max_length=new + 1, **gs)
+        alone_ids.append([int(v) for v in ids[1:, 0]])
+    alone_lat, traces = [], []
+    for j in range(ni):
+        gen = NaiveCache(cfg.layers)
+        gi, kvl, rope = m8.prepare_prompts([0], [0], [str(nv + j)], tok, ntid)
+        gen = m8.forward_cache_update_text(gen, **gi)
+        gl = m8.prepare_vae_latent(kvl, rope, [(hw, hw)], ntid)
+        gl["packed_init_noises"] = noises[j].clone()
+        gt = m8.prepare_vae_latent_cfg([0], [0], [(hw, hw)])
+        gim = m8.prepare_vae_latent_cfg(kvl, rope, [(hw, hw)])
+        tr = []
+        lat = m8.generate_image(past_key_values=gen, cfg_text_past_key_values=NaiveCache(cfg.layers), cfg_img_past_key_values=gen.snapshot(),
+                                callback=lambda i, x: tr.append(x.clone()), **kw, **gl,
+                                cfg_text_packed_position_ids=gt["cfg_packed_position_ids"], cfg_img_packed_position_ids=gim["cfg_packed_position_ids"])
+        alone_lat.append(lat[0].clone())
+        traces.append((tr, kvl, rope))
+
+    # ---- the mixed run
+    srv = MixedBatcher(m8, vae, tok, ntid, ident, slots=nv, t2i_batch=ni, flow_steps_per_round=1, max_context=1100, max_new_tokens=new,
+                       check_every=2)
+    rids = [srv.submit(images[i], str(i), max_new_tokens=new) for i in range(nv)]
+    iids = [srv.submit_t2i(str(nv + j), (hw, hw), init_noise=noises[j], **kw) for j in range(ni)]
+    got = srv.run()
+    assert srv.stats["interleaved_rounds"] >= steps - 1 and srv.stats["decode_steps"] >= new and srv.stats["images"] == ni
+    for rid, ids in zip(rids, alone_ids):
+        want = " ".join(str(v) for v in ids)
+        assert got[rid] == want[:len(got[rid])] and len(got[rid]) > 0, f"VQA request {rid}: {got[rid]!r} vs alone {want!r}"
+    for iid, lat in zip(iids, alone_lat):
+        assert torch.equal(srv.latents[iid], lat), f"T2I request {iid}: latent differs from the request served alone"
+
+    # ---- W8A8 flow passes against the oracle (per image: the engine's batch semantics of 'global' renorm are per sample)
+    worst, devs = 0.0, []
+    for j in range(ni):
+        tr, kvl, rope = traces[j]
+        og = KVCache(cfg.layers, 1)
+        okv, orope = o8.update_text(og, [0], [0], [[ntid["bos_token_id"]] + table[nv + j] + [ntid["eos_token_id"]]])
+        assert okv == kvl and orope == rope
+        otr = []
+        olat = o8.generate_image(og, [rope[0]], [(hw, hw)], noises[j], ntid, num_timesteps=steps, timestep_shift=3.0, cfg_interval=(0.4, 1.0),
+                                 cfg_text_scale=4.0, cfg_text=(KVCache(cfg.layers, 1), [0]), cfg_img_scale=1.5, cfg_img=(og.clone(), [rope[0]]),
+                                 cfg_renorm_min=0.0, cfg_renorm_type="global", trace=otr)
+        for x, ox in zip(tr, otr):
+            d = (x.cpu() - ox).abs()
+            worst = max(worst, d.max().item())
+            devs.append(d.flatten())
+        px = got[iids[j]]
+        ref = o8.decode_image(olat[0], (hw, hw))
+        diff = (px.int() - ref.int()).abs()
+        dist = {k: round(100 * (diff <= k).float().mean().item(), 2) for k in (1, 2, 4, 8, 16)}
+        print(f"configs[4] mixed, image {j}: uint8 pixels within k levels of the W8A8 oracle's {dist}, max {diff.max().item()}")
+        # measured (MI355X, round 3): 27-30 % within 1 level, 61-65 % within 4, 86.5-89 % within 8, 99.4-99.6 % within 16, max 26-29
+        assert dist[16] >= 98.5 and dist[8] >= 75.0, f"W8A8 pixels image {j}: {dist}"
+    allv = torch.cat(devs)
+    q = torch.quantile(allv[torch.randperm(allv.numel())[:2_000_000]].float(), torch.tensor([0.5, 0.9, 0.99]))
+    scale = max(float(t.abs().max()) for t in traces[0][0])
+    print(f"configs[4] mixed W8A8 T2I full width: latent deviation vs the oracle over {steps - 1} Euler steps: max {worst:.4f}, mean "
+          f"{allv.mean().item():.5f}, p50 / p90 / p99 = {q[0]:.4f} / {q[1]:.4f} / {q[2]:.4f} (latent range {scale:.2f})")
+    # rounding to e4m3 is a step function: a 1-ulp bf16 difference upstream can move an activation by a whole e4m3 step (2^-3
+    # relative), and the guided steps amplify velocity differences ~6x.  Measured (MI355X, round 3): max 0.43, mean 0.039, p99 0.22
+    # on latents of range 6.4; bounds = 2x that (DESIGN.md section 3)
+    assert worst <= 0.9 and allv.mean().item() <= 0.08, f"W8A8 latents: max {worst} mean {allv.mean().item()}"
     del m8
     torch.cuda.empty_cache()

@@ -246,95 +246,21 @@ class Bagel(BagelPrep):
                        cfg_text_key_values_lens=None, cfg_text_packed_key_value_indexes=None,
                        cfg_img_scale: float = 1.0, cfg_img_packed_query_indexes=None, cfg_img_packed_position_ids=None,
                        cfg_img_past_key_values: Optional[NaiveCache] = None, cfg_img_key_values_lens=None,
-                       cfg_img_packed_key_value_indexes=None, cfg_type: str = "parallel", callback=None):
-        """Rectified-flow Euler sampler with dual CFG + renorm (bagel.py:901-986, 989-1211)."""
-        if cfg_renorm_type not in ("global", "channel", "text_channel"):
-            raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
-        dev = self.device
-        lm, g = self.language_model, self.glue
-        x_t = packed_init_noises.to(device=dev, dtype=torch.float32).contiguous().clone()
-        N, D = x_t.shape
-        seqlens = [int(v) for v in packed_seqlens.tolist()]
-        T = sum(seqlens)
-        # schedule on the host in fp32, exactly as the reference builds it (bagel.py:937-940)
-        ts = torch.linspace(1, 0, num_timesteps)
-        ts = timestep_shift * ts / (1 + (timestep_shift - 1) * ts)
-        dts = ts[:-1] - ts[1:]
-        ts = ts[:-1]
-        t_emb_all = self.time_embed(ts)                           # rows identical within a step: compute once
-        text_rows = packed_text_indexes.to(device=dev, dtype=torch.int32)
-        vae_rows = packed_vae_token_indexes.to(device=dev, dtype=torch.int32)
-        vae_pos = packed_vae_position_ids.to(device=dev, dtype=torch.int64)
-        seg_off = [0]
-        for n in seqlens:
-            seg_off.append(seg_off[-1] + n - 2)
-        seg_off_d = torch.tensor(seg_off, dtype=torch.int32).to(dev)
-        # The reference runs the conditional, no-text and no-image passes one after another
-        # (bagel.py:1120-1171).  They share the query tokens and the weights and differ only in their KV
-        # context, and samples are independent, so here they are ONE packed forward over nctx*B segments
-        # of a merged cache: the weights stream once instead of three times and the GEMMs see 3x the rows.
-        B = len(seqlens)
-        use_text = cfg_text_scale > 1.0
-        use_img = use_text and cfg_img_scale > 1.0   # the reference computes the image pass but drops it when
-        ctxs = [(past_key_values, packed_position_ids)]                      # cfg_text_scale <= 1 (bagel.py:1173,1208)
-        if use_text:
-            ctxs.append((cfg_text_past_key_values, cfg_text_packed_position_ids))
-        # Pure text-to-image: the "no image" context holds exactly the tokens of the conditional one
-        # (inferencer.py:587,602), so its velocity equals v_t bit for bit (same rows through the same
-        # deterministic kernels).  When the two caches and position ids are PROVABLY identical the third pass
-        # is skipped and v_img := v_t; the CFG arithmetic is unchanged (SURVEY.md appendix A).
-        img_same = use_img and self._contexts_identical(past_key_values, packed_position_ids,
-                                                        cfg_img_past_key_values, cfg_img_packed_position_ids)
-        if use_img and not img_same:
-            ctxs.append((cfg_img_past_key_values, cfg_img_packed_position_ids))
-        nctx = len(ctxs)
-        cfgm = self.cfg
-        for c, _ in ctxs:
-            if c is None:
-                raise ValueError("classifier-free guidance needs the cfg_* contexts")
-        if key_values_lens is not None and past_key_values.slabs is not None and \
-                [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
-            raise ValueError("key_values_lens disagree with the cache")
-        if nctx > 1:
-            merged = NaiveCache.merged([c for c, _ in ctxs], [B] * nctx, max(seqlens), cfgm.kv_heads, cfgm.head_dim, dev)
-            base = merged.view_segments(0, B)
-        else:
-            merged = base = past_key_values
-        seq_all = torch.zeros((nctx * T, self.hidden_size), dtype=BF16, device=dev)
-        rows_text = torch.cat([text_rows + c * T for c in range(nctx)])
-        rows_vae = torch.cat([vae_rows + c * T for c in range(nctx)])
-        lm.embed_tokens(packed_text_ids.repeat(nctx), out=seq_all, out_rows=rows_text)
-        pos_all = torch.cat([p.to(torch.long).cpu() for _, p in ctxs])
-        seqlens_all = torch.tensor(seqlens * nctx, dtype=torch.int)
-        seq1 = seq_all[:T]
+                       cfg_img_packed_key_value_indexes=None, cfg_type: str = "parallel", callback=None,
+                       cfg_renorm_batch_semantics: str = "per_sample"):
+        """Rectified-flow Euler sampler with dual CFG + renorm (bagel.py:901-986, 989-1211).
 
-        def forward(n, cache):
-            out = lm.forward_inference(
-                packed_query_sequence=seq_all[:n * T], query_lens=seqlens_all[:n * B],
-                packed_query_position_ids=pos_all[:n * T], past_key_values=cache, update_past_key_values=False,
-                is_causal=False, mode="gen", packed_vae_token_indexes=rows_vae[:n * N], packed_text_indexes=rows_text[:n * 2 * B])
-            return ops.gemm(out.packed_query_sequence, g.llm2vae)          # [n*T, D]; vae rows picked by the CFG kernel
-
-        rtype = {"global": 0, "channel": 1, "text_channel": 2}[cfg_renorm_type]
-        for i in range(len(ts)):
-            t = float(ts[i])
-            guided = use_text and t > cfg_interval[0] and t <= cfg_interval[1]
-            s_text, s_img = (cfg_text_scale, cfg_img_scale) if guided else (1.0, 1.0)
-            xb = ops.cast_pad(x_t, D)
-            h = ops.gemm(xb, g.vae2llm)
-            for c in range(nctx if guided else 1):
-                ops.add_rows(h, seq_all[c * T:(c + 1) * T], bcast=t_emb_all[i], table=g.latent_pos, idx=vae_pos, out_rows=vae_rows)
-            if guided:
-                v = forward(nctx, merged)
-                v_t, v_text = v[:T], v[T:2 * T]
-                v_img = (v_t if img_same else v[2 * T:3 * T]) if use_img else None
-            else:
-                v_t, v_text, v_img = forward(1, base), None, None
-            ops.cfg_renorm_euler(x_t, v_t, v_text, v_img, vae_rows, seg_off_d, B, s_text, s_img if use_img else 1.0,
-                                 cfg_renorm_min, rtype, float(dts[i]))
+        cfg_renorm_batch_semantics (only matters for cfg_renorm_type="global" with more than one sample in the packed batch):
+        "per_sample" (default) takes the renorm norms per sample, i.e. a packed call equals B single-sample calls - the only
+        way the reference's inferencer calls this method (inferencer.py:165-232) and what keeps a request's image independent
+        of how a batch is sharded over GPUs; "reference" reproduces bagel.py:1196-1198 literally: ONE norm over all the
+        latent tokens of the packed batch, which couples the samples."""
+        sess = FlowSession(self, locals())
+        while not sess.finished:
+            sess.step(1)
             if callback is not None:
-                callback(i, x_t)
-        return x_t.split([n - 2 for n in seqlens])
+                callback(sess.i - 1, sess.x_t)
+        return sess.latents()
 
     @staticmethod
     def _contexts_identical(ca, pos_a, cb, pos_b):
@@ -444,3 +370,155 @@ class Bagel(BagelPrep):
                                  temperature=temperature, end_token_id=new_token_ids["eos_token_id"], **gi)
         output = tokenizer.decode(ids[:, 0].cpu())
         return output.split("<|im_end|>")[0].split("<|im_start|>")[1]
+
+
+class FlowSession:
+    """The rectified-flow sampler of Bagel.generate_image (bagel.py:901-986, 989-1211) as a RESUMABLE object: the setup of
+    generate_image, then `step(n)` = n Euler steps.  generate_image runs it to the end; the mixed VQA + T2I scheduler
+    (serving.MixedBatcher, BASELINE.json configs[4]) interleaves its steps with the decode steps of the VQA slots."""
+
+    def __init__(self, model, a):
+        m = self.m = model
+        packed_text_ids, packed_text_indexes = a["packed_text_ids"], a["packed_text_indexes"]
+        packed_init_noises, packed_vae_position_ids = a["packed_init_noises"], a["packed_vae_position_ids"]
+        packed_vae_token_indexes, packed_seqlens, packed_position_ids = a["packed_vae_token_indexes"], a["packed_seqlens"], a["packed_position_ids"]
+        past_key_values, key_values_lens = a["past_key_values"], a["key_values_lens"]
+        num_timesteps, timestep_shift = a["num_timesteps"], a["timestep_shift"]
+        cfg_renorm_type, cfg_text_scale, cfg_img_scale = a["cfg_renorm_type"], a["cfg_text_scale"], a["cfg_img_scale"]
+        cfg_text_past_key_values, cfg_text_packed_position_ids = a["cfg_text_past_key_values"], a["cfg_text_packed_position_ids"]
+        cfg_img_past_key_values, cfg_img_packed_position_ids = a["cfg_img_past_key_values"], a["cfg_img_packed_position_ids"]
+        self.cfg_interval, self.cfg_renorm_min = a["cfg_interval"], a["cfg_renorm_min"]
+        self.cfg_text_scale, self.cfg_img_scale = cfg_text_scale, cfg_img_scale
+        batch_sem = a.get("cfg_renorm_batch_semantics", "per_sample")
+        if batch_sem not in ("per_sample", "reference"):
+            raise ValueError(f"cfg_renorm_batch_semantics must be 'per_sample' or 'reference', got {batch_sem!r}")
+        self._setup(model, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
+                           packed_vae_token_indexes, packed_seqlens, packed_position_ids, past_key_values, key_values_lens,
+                           num_timesteps, timestep_shift, cfg_renorm_type, cfg_text_scale, cfg_text_past_key_values,
+                           cfg_text_packed_position_ids, cfg_img_scale, cfg_img_past_key_values, cfg_img_packed_position_ids, batch_sem)
+
+    def _setup(self, m, packed_text_ids, packed_text_indexes, packed_init_noises, packed_vae_position_ids,
+               packed_vae_token_indexes, packed_seqlens, packed_position_ids, past_key_values, key_values_lens,
+               num_timesteps, timestep_shift, cfg_renorm_type, cfg_text_scale, cfg_text_past_key_values,
+               cfg_text_packed_position_ids, cfg_img_scale, cfg_img_past_key_values, cfg_img_packed_position_ids, batch_sem):
+        s = self     # (m = the Bagel model; the body below is generate_image's former setup)
+        if cfg_renorm_type not in ("global", "channel", "text_channel"):
+            raise NotImplementedError(f"{cfg_renorm_type} is not suppoprted")
+        dev = m.device
+        lm, g = m.language_model, m.glue
+        x_t = packed_init_noises.to(device=dev, dtype=torch.float32).contiguous().clone()
+        N, D = x_t.shape
+        seqlens = [int(v) for v in packed_seqlens.tolist()]
+        T = sum(seqlens)
+        # schedule on the host in fp32, exactly as the reference builds it (bagel.py:937-940)
+        ts = torch.linspace(1, 0, num_timesteps)
+        ts = timestep_shift * ts / (1 + (timestep_shift - 1) * ts)
+        dts = ts[:-1] - ts[1:]
+        ts = ts[:-1]
+        t_emb_all = m.time_embed(ts)                           # rows identical within a step: compute once
+        text_rows = packed_text_indexes.to(device=dev, dtype=torch.int32)
+        vae_rows = packed_vae_token_indexes.to(device=dev, dtype=torch.int32)
+        vae_pos = packed_vae_position_ids.to(device=dev, dtype=torch.int64)
+        seg_off = [0]
+        for n in seqlens:
+            seg_off.append(seg_off[-1] + n - 2)
+        seg_off_d = torch.tensor(seg_off, dtype=torch.int32).to(dev)
+        # The reference runs the conditional, no-text and no-image passes one after another
+        # (bagel.py:1120-1171).  They share the query tokens and the weights and differ only in their KV
+        # context, and samples are independent, so here they are ONE packed forward over nctx*B segments
+        # of a merged cache: the weights stream once instead of three times and the GEMMs see 3x the rows.
+        B = len(seqlens)
+        use_text = cfg_text_scale > 1.0
+        use_img = use_text and cfg_img_scale > 1.0   # the reference computes the image pass but drops it when
+        ctxs = [(past_key_values, packed_position_ids)]                      # cfg_text_scale <= 1 (bagel.py:1173,1208)
+        if use_text:
+            ctxs.append((cfg_text_past_key_values, cfg_text_packed_position_ids))
+        # Pure text-to-image: the "no image" context holds exactly the tokens of the conditional one
+        # (inferencer.py:587,602), so its velocity equals v_t bit for bit (same rows through the same
+        # deterministic kernels).  When the two caches and position ids are PROVABLY identical the third pass
+        # is skipped and v_img := v_t; the CFG arithmetic is unchanged (SURVEY.md appendix A).
+        img_same = use_img and m._contexts_identical(past_key_values, packed_position_ids,
+                                                        cfg_img_past_key_values, cfg_img_packed_position_ids)
+        if use_img and not img_same:
+            ctxs.append((cfg_img_past_key_values, cfg_img_packed_position_ids))
+        nctx = len(ctxs)
+        cfgm = m.cfg
+        for c, _ in ctxs:
+            if c is None:
+                raise ValueError("classifier-free guidance needs the cfg_* contexts")
+        if key_values_lens is not None and past_key_values.slabs is not None and \
+                [int(v) for v in key_values_lens.tolist()] != list(past_key_values.lens):
+            raise ValueError("key_values_lens disagree with the cache")
+        if nctx > 1:
+            merged = NaiveCache.merged([c for c, _ in ctxs], [B] * nctx, max(seqlens), cfgm.kv_heads, cfgm.head_dim, dev)
+            base = merged.view_segments(0, B)
+        else:
+            merged = base = past_key_values
+        seq_all = torch.zeros((nctx * T, m.hidden_size), dtype=BF16, device=dev)
+        rows_text = torch.cat([text_rows + c * T for c in range(nctx)])
+        rows_vae = torch.cat([vae_rows + c * T for c in range(nctx)])
+        lm.embed_tokens(packed_text_ids.repeat(nctx), out=seq_all, out_rows=rows_text)
+        pos_all = torch.cat([p.to(torch.long).cpu() for _, p in ctxs])
+        seqlens_all = torch.tensor(seqlens * nctx, dtype=torch.int)
+        seq1 = seq_all[:T]
+
+        def forward(n, cache):
+            out = lm.forward_inference(
+                packed_query_sequence=seq_all[:n * T], query_lens=seqlens_all[:n * B],
+                packed_query_position_ids=pos_all[:n * T], past_key_values=cache, update_past_key_values=False,
+                is_causal=False, mode="gen", packed_vae_token_indexes=rows_vae[:n * N], packed_text_indexes=rows_text[:n * 2 * B])
+            return ops.gemm(out.packed_query_sequence, g.llm2vae)          # [n*T, D]; vae rows picked by the CFG kernel
+
+        s.rtype = {"global": 0, "channel": 1, "text_channel": 2}[cfg_renorm_type]
+        if batch_sem == "reference" and s.rtype == 0 and B > 1:
+            # bagel.py:1196-1198: ONE norm over every latent token of the packed batch
+            seg_off_d = torch.tensor([0, N], dtype=torch.int32).to(dev)
+            s.renorm_segments = 1
+        else:
+            s.renorm_segments = B
+        s.x_t, s.D, s.T, s.N, s.B, s.nctx = x_t, D, T, N, B, nctx
+        s.ts, s.dts, s.t_emb_all = ts, dts, t_emb_all
+        s.use_text, s.use_img, s.img_same = use_text, use_img, img_same
+        s.seq_all, s.vae_pos, s.vae_rows, s.seg_off_d = seq_all, vae_pos, vae_rows, seg_off_d
+        s.merged, s.base, s.forward, s.seqlens = merged, base, forward, seqlens
+        s.i = 0
+        return s
+
+    @property
+    def finished(self):
+        return self.i >= len(self.ts)
+
+    @property
+    def steps_left(self):
+        return len(self.ts) - self.i
+
+    @torch.no_grad()
+    def step(self, n=1):
+        """n Euler steps (fewer if the schedule ends)."""
+        s, m = self, self.m
+        g = m.glue
+        with ops.device_scope(m.device):
+            for _ in range(n):
+                if s.finished:
+                    return
+                i = s.i
+                t = float(s.ts[i])
+                guided = s.use_text and t > s.cfg_interval[0] and t <= s.cfg_interval[1]
+                s_text, s_img = (s.cfg_text_scale, s.cfg_img_scale) if guided else (1.0, 1.0)
+                xb = ops.cast_pad(s.x_t, s.D)
+                h = ops.gemm(xb, g.vae2llm)
+                T = s.T
+                for c in range(s.nctx if guided else 1):
+                    ops.add_rows(h, s.seq_all[c * T:(c + 1) * T], bcast=s.t_emb_all[i], table=g.latent_pos, idx=s.vae_pos, out_rows=s.vae_rows)
+                if guided:
+                    v = s.forward(s.nctx, s.merged)
+                    v_t, v_text = v[:T], v[T:2 * T]
+                    v_img = (v_t if s.img_same else v[2 * T:3 * T]) if s.use_img else None
+                else:
+                    v_t, v_text, v_img = s.forward(1, s.base), None, None
+                ops.cfg_renorm_euler(s.x_t, v_t, v_text, v_img, s.vae_rows, s.seg_off_d, s.renorm_segments, s_text,
+                                     s_img if s.use_img else 1.0, s.cfg_renorm_min, s.rtype, float(s.dts[i]))
+                s.i += 1
+
+    def latents(self):
+        return self.x_t.split([n - 2 for n in self.seqlens])

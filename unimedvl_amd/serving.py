@@ -87,10 +87,14 @@ class ContinuousBatcher:
         sess = DecodeSession(m.language_model, cache, start, pos, self.check_every, use_graph=self.use_graph,
                              do_sample=self.do_sample, temperature=self.temperature, seed=seed)
         cache.lens = lens_now                           # the session only reads them; this loop owns the bookkeeping
-        while any(r is not None for r in active):
+        while any(r is not None for r in active) or self._other_work():
+            if not any(r is not None for r in active):  # only the other kind of work is left (MixedBatcher: flow passes)
+                self._between_rounds()
+                continue
             k = self.check_every
             sess.rewind_outputs()
             sess.step(k)
+            self._between_rounds()                      # (queued behind the decode steps; the host reads the ids after both)
             self.stats["decode_steps"] += k
             ids = sess.pred_ids[:k].cpu()               # [k, B]; the only host sync of the round
             freed = []
@@ -124,6 +128,13 @@ class ContinuousBatcher:
             for b, (tok, kvl, rope) in zip(freed, self._prefill_many(freed, [active[b] for b in freed])):
                 sess.set_slot(b, tok, kvl, rope)
         return dict(self.results)
+
+    # ------------------------------------------------------------------ hooks (MixedBatcher)
+    def _other_work(self) -> bool:
+        return False
+
+    def _between_rounds(self):
+        pass
 
     # ------------------------------------------------------------------ internals
     def _prefill(self, b: int, req: _Request):
@@ -198,3 +209,124 @@ class ContinuousBatcher:
         text = self.tokenizer.decode(torch.tensor([bos] + req.tokens, dtype=torch.int64))
         self.results[req.rid] = text.split("<|im_end|>")[0].split("<|im_start|>")[1]   # inferencer.py:277-278
         self.stats["tokens"] += len(req.tokens)
+
+
+@dataclass
+class _T2IRequest:
+    rid: int
+    prompt: str
+    image_shape: Any
+    params: tuple              # (num_timesteps, timestep_shift, cfg_text_scale, cfg_img_scale, cfg_interval, renorm_min, renorm_type)
+    noise: Optional[torch.Tensor] = None
+
+
+class MixedBatcher(ContinuousBatcher):
+    """VQA decode slots AND text-to-image jobs in one step stream - BASELINE.json configs[4] ("mixed VQA + T2I interleaved
+    batch"; with cfg.llm_weight_dtype = "fp8" the decode steps stream the e4m3 images and, with llm_act_dtype = "fp8", the
+    flow passes run on the fp8 matrix instruction).
+
+    The reference interleaves understanding and generation inside ONE request's context loop (inferencer.py:552-637: text
+    and image items update the context in order, then either gen_text or gen_image runs) and serves one request at a time.
+    Here requests of both kinds are in flight together: a round of the serving loop is `check_every` captured decode steps
+    for all VQA slots (Bagel.generate_text, bagel.py:1236-1317) followed by `flow_steps_per_round` Euler steps of the active
+    text-to-image group (Bagel.generate_image, bagel.py:901-1211: each guided step is one packed forward over the
+    conditional / no-text / no-image contexts of every image of the group), all queued on the same stream before the host
+    looks at the new token ids.  Retired VQA slots are refilled in flight as in ContinuousBatcher; a finished image group is
+    decoded by the VAE in one batch (inferencer.py:234-256) and the next group of queued prompts is admitted.
+
+    Samples are independent rows of every kernel and the two kinds of work share nothing but the weights, so every answer
+    and every image equals what the request gets when it is served alone (tests/test_serving_gpu.py, test_fullwidth_gpu.py)."""
+
+    def __init__(self, model, vae_model, tokenizer, new_token_ids, image_transform, slots: int = 8, t2i_batch: int = 4,
+                 flow_steps_per_round: int = 2, **kw):
+        super().__init__(model, tokenizer, new_token_ids, image_transform, slots=slots, **kw)
+        self.vae = vae_model
+        self.t2i_batch, self.flow_steps_per_round = int(t2i_batch), int(flow_steps_per_round)
+        self.t2i_queue: Deque[_T2IRequest] = deque()
+        self._flow = None                 # (FlowSession, [requests]) of the active group
+        self.stats.update({"flow_steps": 0, "images": 0, "t2i_groups": 0, "interleaved_rounds": 0})
+
+    def submit_t2i(self, prompt: str, image_shape=(256, 256), num_timesteps: int = 50, timestep_shift: float = 3.0,
+                   cfg_text_scale: float = 4.0, cfg_img_scale: float = 1.5, cfg_interval=(0.4, 1.0), cfg_renorm_min: float = 0.0,
+                   cfg_renorm_type: str = "global", init_noise: Optional[torch.Tensor] = None) -> int:
+        """Queue a text-to-image request (the defaults are interactive_image_generator.py:303-306's).  init_noise (optional,
+        [h*w, patch*patch*z]) fixes the starting latent; otherwise it is drawn from torch's CPU generator at admission,
+        as the reference does (bagel.py:893)."""
+        rid = self._next_id
+        self._next_id += 1
+        params = (int(num_timesteps), float(timestep_shift), float(cfg_text_scale), float(cfg_img_scale),
+                  tuple(float(v) for v in cfg_interval), float(cfg_renorm_min), str(cfg_renorm_type))
+        self.t2i_queue.append(_T2IRequest(rid, prompt, tuple(int(v) for v in image_shape), params, init_noise))
+        return rid
+
+    # ------------------------------------------------------------------ the flow side of a round
+    def _other_work(self) -> bool:
+        return self._flow is not None or bool(self.t2i_queue)
+
+    def _admit_t2i(self):
+        """The next group: up to t2i_batch queued prompts with the same image shape and sampler parameters."""
+        first = self.t2i_queue[0]
+        group, rest = [], deque()
+        while self.t2i_queue:
+            r = self.t2i_queue.popleft()
+            if len(group) < self.t2i_batch and r.image_shape == first.image_shape and r.params == first.params:
+                group.append(r)
+            else:
+                rest.append(r)
+        self.t2i_queue = rest
+        m, ntid, n = self.model, self.new_token_ids, len(group)
+        steps, shift, s_text, s_img, interval, rmin, rtype = first.params
+        shapes = [first.image_shape] * n
+        # gen context = the prompt; no-text context = empty; no-image context = the prompt again (inferencer.py:583-607)
+        gen = NaiveCache(m.cfg.layers)
+        gi, kvl, rope = m.prepare_prompts([0] * n, [0] * n, [r.prompt for r in group], self.tokenizer, ntid)
+        gen = m.forward_cache_update_text(gen, **gi)
+        gl = m.prepare_vae_latent(kvl, rope, shapes, ntid)
+        if any(r.noise is not None for r in group):
+            parts = list(gl["packed_init_noises"].split([gl["packed_init_noises"].shape[0] // n] * n))
+            for j, r in enumerate(group):
+                if r.noise is not None:
+                    parts[j] = r.noise.to(parts[j].dtype).reshape(parts[j].shape)
+            gl["packed_init_noises"] = torch.cat(parts, 0)
+        gt = m.prepare_vae_latent_cfg([0] * n, [0] * n, shapes)
+        gim = m.prepare_vae_latent_cfg(kvl, rope, shapes)
+        from .bagel import FlowSession
+        args = dict(gl)
+        args.update(dict(
+            past_key_values=gen, key_values_lens=gl.get("key_values_lens"), num_timesteps=steps, timestep_shift=shift,
+            cfg_renorm_min=rmin, cfg_renorm_type=rtype, cfg_interval=interval, cfg_text_scale=s_text, cfg_img_scale=s_img,
+            cfg_text_past_key_values=NaiveCache(m.cfg.layers), cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+            cfg_img_past_key_values=gen.snapshot(), cfg_img_packed_position_ids=gim["cfg_packed_position_ids"]))
+        self._flow = (FlowSession(m, args), group)
+        self.stats["t2i_groups"] += 1
+
+    def _between_rounds(self):
+        if self._flow is None:
+            if not self.t2i_queue:
+                return
+            self._admit_t2i()
+        flow, group = self._flow
+        before = flow.i
+        flow.step(self.flow_steps_per_round)
+        self.stats["flow_steps"] += flow.i - before
+        self.stats["interleaved_rounds"] += 1
+        if flow.finished:
+            m = self.model
+            lats = list(flow.latents())
+            px = self.vae.decode_tokens_batch_to_uint8(lats, group[0].image_shape, m.latent_downsample, m.latent_patch_size)
+            for j, r in enumerate(group):
+                self.results[r.rid] = px[j].cpu()
+                self.latents[r.rid] = lats[j].clone()
+            self.stats["images"] += len(group)
+            self._flow = None
+
+    def run(self):
+        """Serve everything submitted: {request id: answer text | uint8 [H, W, 3] image}; self.latents keeps the final latent
+        tokens of every image (tests compare them with the requests served alone)."""
+        self.latents: Dict[int, torch.Tensor] = {}
+        if self.queue:
+            return super().run()
+        with torch.no_grad(), ops.device_scope(self.device):
+            while self._other_work():          # no VQA request at all: only image groups
+                self._between_rounds()
+        return dict(self.results)
