@@ -267,12 +267,8 @@ class Comm:
         out.copy_(torch.cat(parts, 0))
 
 
-def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128, num_timesteps=50):
-    """BASELINE.json configs[2]: text-to-image, 50 diffusion steps, 256x256, batch 4 per GPU, the reference
-    defaults of InterleaveInferencer.gen_image (cfg_text 4.0, cfg_img 1.5, interval (0.4,1], shift 3.0, global
-    renorm): 49 Euler steps, 131 LLM gen-mode passes of 258 query tokens per image, then VAE decode to uint8."""
-    from copy import deepcopy
-    from unimedvl_amd.kvcache import NaiveCache
+def synth_vae(cfg, dev):
+    """the full-size AutoEncoder with random fan-in-scaled weights (no checkpoint, no network)"""
     from unimedvl_amd.shapes import vae_shapes
     from unimedvl_amd.vae import AutoEncoder
     shapes = vae_shapes(cfg.to_dict())
@@ -286,7 +282,72 @@ def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128,
         for d in shp[1:]:
             fan_in *= d
         return (torch.randn(shp, device=dev, generator=vgen) / math.sqrt(fan_in)).to(torch.bfloat16)
-    vae = AutoEncoder(cfg, vget, device=dev)
+    return AutoEncoder(cfg, vget, device=dev)
+
+
+class IdTokenizerRT(IdTokenizer):
+    """IdTokenizer whose decode() returns the ids as text in the chat frame the batcher strips (inferencer.py:277-278)"""
+
+    def decode(self, ids):
+        return "<|im_start|>" + " ".join(str(int(v)) for v in ids[1:]) + "<|im_end|>"
+
+
+def run_mixed(model, cfg, dev, rank, world, dist, n_vqa=8, n_t2i=4, new_tokens=128, hw=256, num_timesteps=50, img_hw=448):
+    """BASELINE.json configs[4] as written: a MIXED VQA + T2I batch, interleaved, on the fp8 model: serving.MixedBatcher keeps
+    n_vqa VQA requests (448x448 image + 32-token question, `new_tokens` greedy tokens each) decoding in their slots while a
+    group of n_t2i text-to-image requests (256x256, 50 steps, default guidance) advances two Euler steps per round on the
+    same stream; the image group's VAE decode is part of the timed region, and so are the VQA prefills."""
+    from unimedvl_amd.serving import MixedBatcher
+    vae = synth_vae(cfg, dev)
+    ntid = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
+    g = torch.Generator().manual_seed(777 + rank)
+    hi = min(150000, cfg.vocab - 8)
+    table = [torch.randint(min(1000, hi // 2), hi, (32,), generator=g).tolist() for _ in range(n_vqa)] + \
+            [torch.randint(min(1000, hi // 2), hi, (128,), generator=g).tolist() for _ in range(n_t2i)]
+    tok = IdTokenizerRT(table)
+    images = [synth_image(img_hw, img_hw, 9000 + 100 * rank + i) for i in range(n_vqa)]
+
+    def once(nt, steps):
+        srv = MixedBatcher(model, vae, tok, ntid, lambda x: x, slots=n_vqa, t2i_batch=n_t2i, flow_steps_per_round=2,
+                           max_context=(img_hw // 14) ** 2 + 2 + 34 + 8, max_new_tokens=nt, check_every=8)
+        for i in range(n_vqa):
+            srv.submit(images[i], str(i), max_new_tokens=nt)
+        torch.manual_seed(11 + rank)
+        for j in range(n_t2i):
+            srv.submit_t2i(str(n_vqa + j), (hw, hw), num_timesteps=steps)
+        out = srv.run()
+        return srv, out
+    once(8, 3)                                 # warm-up: allocator, graph capture path, lazy module load
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    srv, res = once(new_tokens, num_timesteps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        el = dist.max(el)
+    n_img = sum(1 for v in res.values() if isinstance(v, torch.Tensor))
+    assert n_img == n_t2i and srv.stats["tokens"] > 0
+    return {"workload": f"configs[4]: mixed batch on e4m3 weights - {n_vqa} VQA requests ({img_hw}x{img_hw} + 32-token question, up to "
+                        f"{new_tokens} greedy tokens) and {n_t2i} text-to-image requests ({hw}x{hw}, {num_timesteps} steps) interleaved "
+                        "in one step stream (serving.MixedBatcher), per GPU",
+            "wall_s": round(el, 3), "vqa_tokens": int(srv.stats["tokens"]) * world, "images": n_img * world,
+            "vqa_tokens_per_s": round(world * srv.stats["tokens"] / el, 1), "images_per_s": round(world * n_img / el, 3),
+            "decode_steps": srv.stats["decode_steps"], "flow_steps": srv.stats["flow_steps"],
+            "interleaved_rounds": srv.stats["interleaved_rounds"],
+            "includes": "VQA ViT + prefill, decode rounds of 8 graph steps, 2 Euler steps per round, VAE decode of the image group"}
+
+
+def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128, num_timesteps=50):
+    """BASELINE.json configs[2]: text-to-image, 50 diffusion steps, 256x256, batch 4 per GPU, the reference
+    defaults of InterleaveInferencer.gen_image (cfg_text 4.0, cfg_img 1.5, interval (0.4,1], shift 3.0, global
+    renorm): 49 Euler steps, 131 LLM gen-mode passes of 258 query tokens per image, then VAE decode to uint8."""
+    from copy import deepcopy
+    from unimedvl_amd.kvcache import NaiveCache
+    vae = synth_vae(cfg, dev)
     ntid = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
     g = torch.Generator().manual_seed(99 + rank)
     hi = min(150000, cfg.vocab - 8)
@@ -676,6 +737,14 @@ def main():
             t8 = run_t2i(model8, cfg8, dev, rank, world, dist, num_timesteps=args.t2i_steps)
             out["decode_fp8_weights"]["t2i_images_per_s_same_model"] = t8["images_per_s"]
             out["decode_fp8_weights"]["t2i_llm_tflops"] = t8["llm_tflops"]
+            try:
+                out["mixed_fp8"] = run_mixed(model8, cfg8, dev, rank, world, dist, num_timesteps=args.t2i_steps)
+                # what the two kinds of work cost back to back on the same model (the separate legs above)
+                sep = out["mixed_fp8"]["vqa_tokens"] / max(out["decode_fp8_weights"]["tokens_per_s"], 1e-9) + \
+                    out["mixed_fp8"]["images"] / max(t8["images_per_s"], 1e-9) + l8["t_prefill"]
+                out["mixed_fp8"]["separate_legs_s"] = round(sep, 3)
+            except Exception as e:   # an extra leg must never take the bench line down
+                out["mixed_fp8"] = {"failed": f"{type(e).__name__}: {e}"}
         del model8, l8
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
