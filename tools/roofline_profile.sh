@@ -1,0 +1,61 @@
+#!/bin/bash
+# One profile of the headline decode step that bench.py's `roofline` object audits itself against:
+#   pass A  rocprofv3 --kernel-trace --stats of a 512-step graph decode  -> per-kernel in-graph average durations
+#   pass B  rocprofv3 --pmc FETCH_SIZE (its own pass, MI355X_MICROARCH.md "HBM": x1024 x2 on gfx950)
+#   pass C  rocprofv3 --pmc WRITE_SIZE (uncalibrated; reported raw)
+# Everything lands in gpurun_out/<tag>_roofline_profile.json, stamped with the sha256 of the kernel sources + build flags
+# (unimedvl_amd/lib/build.stamp): bench.py uses the file only while that stamp equals the library it is running.
+# usage (inside gpurun): bash tools/roofline_profile.sh <tag>     then, in the build container:
+#   cp gpurun_out/<tag>_roofline_profile.json profiles/ && cp gpurun_out/<tag>_roofline_profile.json profiles/roofline_profile_latest.json
+set -e
+TAG=${1:-r03}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ARGS="--no-cpu-baseline --no-t2i --no-fp8 --no-report --no-vit"
+mkdir -p gpurun_out/$TAG/trace gpurun_out/$TAG/FETCH_SIZE gpurun_out/$TAG/WRITE_SIZE
+rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/trace -o bench -- python bench.py $ARGS --steps 512 --warmup 8 > gpurun_out/$TAG/trace/bench.log 2>&1 || true
+grep '^{' gpurun_out/$TAG/trace/bench.log > gpurun_out/${TAG}_decode_line_under_rocprof.json || true
+DB=$(ls gpurun_out/$TAG/trace/*results.db 2>/dev/null | head -1)
+python tools/rocpd_stats.py "$DB" gpurun_out/${TAG}_decode_kernel_stats.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d gpurun_out/$TAG/$C -o pmc -- python bench.py $ARGS --steps 4 --warmup 1 > gpurun_out/$TAG/$C/bench.log 2>&1 || true
+done
+python - <<PY
+import csv, glob, json, sqlite3
+tag = "$TAG"
+stamp = open("unimedvl_amd/lib/build.stamp").read().strip()
+kern = {}
+for r in csv.DictReader(open(f"gpurun_out/{tag}_decode_kernel_stats.csv")):
+    kern[r["Name"]] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, min_us=int(r["MinNs"]) / 1e3, share_pct=float(r["Percentage"]))
+pmc = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    dbs = glob.glob(f"gpurun_out/{tag}/{c}/*results.db")
+    if not dbs:
+        continue
+    cur = sqlite3.connect(dbs[0]).cursor()
+    q = """select s.kernel_name, count(*), avg(p.value) from rocpd_pmc_event p join rocpd_kernel_dispatch d on p.event_id = d.event_id
+           join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name order by 3 desc"""
+    try:
+        for name, n, avg in cur.execute(q):
+            pmc.setdefault(name, {})[c] = dict(dispatches=n, avg_kib=avg)
+    except Exception as e:
+        pmc["error_" + c] = str(e)
+line = {}
+try:
+    line = json.loads(open(f"gpurun_out/{tag}_decode_line_under_rocprof.json").read().strip().splitlines()[-1])
+except Exception:
+    pass
+out = dict(code_stamp=stamp, tag=tag, kernels=kern, pmc=pmc,
+           bench_line_under_rocprof={k: line.get(k) for k in ("value", "ms_per_step", "steps", "config")},
+           correction="traffic = FETCH_SIZE (KiB) x 1024 x 2: gfx950's rocprofv3 tallies the 128-byte requests of a 16 B/lane coalesced stream at 64 B "
+                      "(MI355X_MICROARCH.md 'HBM'); WRITE_SIZE is uncalibrated and reported raw (KiB)",
+           commands=["rocprofv3 --kernel-trace --stats -- python bench.py %s --steps 512 --warmup 8" % "$ARGS",
+                     "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py %s --steps 4 --warmup 1" % "$ARGS",
+                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py %s --steps 4 --warmup 1" % "$ARGS"])
+json.dump(out, open(f"gpurun_out/{tag}_roofline_profile.json", "w"), indent=1)
+top = sorted(kern.items(), key=lambda kv: -kv[1]["share_pct"])[:10]
+for n, v in top:
+    f = pmc.get(n, {}).get("FETCH_SIZE", {}).get("avg_kib")
+    print(f"{n[:70]:70s} n={v['calls']:6d} avg={v['avg_us']:8.2f}us {v['share_pct']:6.2f}%  fetch x2 = {(f * 2048 / 1e6 if f else float('nan')):8.2f} MB")
+print("stamp", stamp[:16], "line", line.get("value"), line.get("ms_per_step"))
+PY
+rm -rf gpurun_out/$TAG
