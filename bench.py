@@ -454,14 +454,31 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    cpu_binding = None
     if world > 1:
+        import datetime
         import torch.distributed as tdist
+        from unimedvl_amd.launch import bind_rank_to_gpu_socket
+        # one process per GPU on a 2-socket host: keep the rank's host side on the socket its GPU hangs off
+        cpu_binding = bind_rank_to_gpu_socket(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("UMV_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            tdist.init_process_group("nccl", device_id=dev)
-        else:
-            tdist.init_process_group(backend)
+        try:
+            if backend == "nccl":
+                tdist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=dev)
+                tdist.all_reduce(probe)             # the first collective builds the xGMI rings: fail here, readably, not mid-bench
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce probe returned {probe.item()} on {world} ranks")
+            else:
+                tdist.init_process_group(backend)
+        except Exception as e:
+            raise SystemExit(
+                f"bench.py rank {rank}: cannot bring up the '{backend}' process group over {world} ranks: {type(e).__name__}: {e}\n"
+                "  RCCL needs GPU peer access over xGMI / PCIe and dmabuf IPC: run with HSA_ENABLE_IPC_MODE_LEGACY=0 (set here by "
+                f"default; current value {os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}), one visible GPU per rank "
+                f"(visible: {torch.cuda.device_count()}), MASTER_ADDR=127.0.0.1; UMV_BENCH_BACKEND=gloo runs the same flow over TCP.")
         dist = Comm(tdist, backend, dev)
 
     from unimedvl_amd import ops
@@ -483,8 +500,9 @@ def main():
         img_hw, prompt_len = 56, 8
     cfg.llm_weight_dtype = args.weights
     B = args.batch
-    if args.workload == "configs3" and args.config == "full":
-        B, prompt_len = (32 if args.batch == 8 else args.batch), 128
+    if args.workload == "configs3":      # BASELINE.json configs[3]: 32 samples per GPU (batch 256 over 8 GPUs), 128-token prompts
+        B = 32 if args.batch == 8 else args.batch
+        prompt_len = 128 if args.config == "full" else 12
     t_load = time.time()
     want_t2i = not args.no_t2i
     model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=want_t2i, visual_und=True)
@@ -733,7 +751,7 @@ def main():
                                if args.config == "full" else "tiny smoke config",
                    "c1_gather": args.gather if world > 1 else None,
                    "batch_per_gpu": B, "context_tokens": ctx, "image": f"{img_hw}x{img_hw}", "prompt_tokens": prompt_len,
-                   "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
+                   "parallelism": f"dp{world}", "cpu_binding": cpu_binding, "decode": "hipGraph" if not args.no_graph else "eager",
                    "prefill_s": round(t_prefill, 3), "prefill_cold_s": round(leg["t_prefill_cold"], 3),
                    "prefill_images_per_s": round(world * B / t_prefill, 1),
                    "weights_init_s": round(t_load, 1), "gpu_ms_per_step": round(gpu_ms / args.steps, 4)},

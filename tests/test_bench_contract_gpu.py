@@ -73,3 +73,22 @@ def test_bench_self_launches_two_ranks(gather):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["c1_gather"] == gather
     assert abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) <= 0.02 * d["value"]    # whole-job tokens / slowest rank's seconds
     assert "cpu_baseline" not in d and d["t2i"]["images_per_s"] > 0
+
+
+def test_bench_configs3_workload_two_ranks():
+    """`python bench.py --workload configs3 --gpus 2`: BASELINE.json configs[3] (32 samples per GPU) through the N-rank flow -
+    per-rank CPU binding, rendezvous on 127.0.0.1, 32 samples per rank, ids all-gather, one line with whole-job tokens/s."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PYTHONDONTWRITEBYTECODE="1", UMV_BENCH_BACKEND="gloo", UMV_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--workload", "configs3",
+                        "--steps", "8", "--warmup", "2", "--no-t2i"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["batch_per_gpu"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 32 * 8 / (d["ms_per_step"] * 8e-3)) <= 0.02 * d["value"]
+    b = d["config"]["cpu_binding"]
+    assert b is not None and ("bound" in b)

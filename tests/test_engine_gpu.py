@@ -172,3 +172,28 @@ def test_t2i_nocfg(engine):
                                 timestep_shift=3.0, **gi)
     err = (lat[0].cpu() - g["latent_nocfg"]).abs().max().item()
     assert err < 0.04, f"latent (no cfg) max abs err {err}"
+
+
+def test_sampled_decode_restarts_with_manual_seed(engine):
+    """do_sample (bagel.py:1297-1299): torch.manual_seed(s) - also the SAME s again, the per-sample evaluation pattern -
+    restarts the sampler's stream; without reseeding two calls differ; sampling leaves torch's CPU generator untouched."""
+    from unimedvl_amd.kvcache import NaiveCache
+    g = load_golden("vqa_b1")
+
+    def sample():
+        cache = NaiveCache(engine.cfg.layers)
+        gi, kvl, rope = engine.prepare_vit_images([0], [0], [g["image"]], lambda x: x, NEW_TOKEN_IDS)
+        cache = engine.forward_cache_update_vit(cache, **gi)
+        gs = engine.prepare_start_tokens(kvl, rope, NEW_TOKEN_IDS)
+        return engine.generate_text(past_key_values=cache, max_length=12, do_sample=True, temperature=1.5, **gs)[:, 0].tolist()
+    torch.manual_seed(42)
+    a = sample()
+    before = torch.get_rng_state()
+    b = sample()                     # same generator state, next call: another key
+    assert torch.equal(before, torch.get_rng_state()), "sampling must not consume torch's CPU generator"
+    torch.manual_seed(42)
+    c = sample()
+    torch.manual_seed(43)
+    d = sample()
+    assert a == c, "manual_seed with the same seed must restart the sampler"
+    assert a != b and a != d, "successive calls / other seeds must draw other samples"

@@ -57,3 +57,26 @@ def test_bench_argument_contract():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
+
+
+def test_cpu_binding_plan_follows_the_gpu_socket(tmp_path):
+    """one process per GPU on a 2-socket host (8 GPUs, 4 per socket): every rank gets a disjoint share of ITS socket's CPUs"""
+    from unimedvl_amd.launch import gpu_numa_node, parse_cpulist, plan_cpu_binding, share_of
+    assert parse_cpulist("0-3,8-11\n") == [0, 1, 2, 3, 8, 9, 10, 11] and parse_cpulist("5") == [5] and parse_cpulist("") == []
+    assert share_of(list(range(10)), 0, 3) == [0, 1, 2] and share_of(list(range(10)), 2, 3) == [6, 7, 8, 9]
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = list(range(256))
+    plans = [plan_cpu_binding(r, 8, numa, allowed, node_cpus) for r in range(8)]
+    for r, cpus in enumerate(plans):
+        assert len(cpus) == 32 and set(cpus) <= set(node_cpus[numa[r]])
+    assert len(set().union(*map(set, plans))) == 256                     # disjoint and complete
+    # an affinity mask the job already has (cgroup, taskset) is respected
+    assert set(plan_cpu_binding(1, 8, numa, list(range(0, 32)), node_cpus)) <= set(range(32))
+    # no NUMA information: an even contiguous split
+    assert plan_cpu_binding(3, 4, [-1, -1, -1, -1], list(range(16)), {}) == [12, 13, 14, 15]
+    # sysfs lookup
+    d = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    d.mkdir(parents=True)
+    (d / "numa_node").write_text("1\n")
+    assert gpu_numa_node("0000:C1:00.0", sysfs=str(tmp_path)) == 1 and gpu_numa_node("0000:aa:00.0", sysfs=str(tmp_path)) == -1

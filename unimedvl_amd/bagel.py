@@ -115,7 +115,11 @@ class Bagel(BagelPrep):
         if max(c + q for c, q in zip(cache.lens, qlens)) > cache.cap:
             return None                          # would re-allocate: the eager path handles (and reports) that
         pos = gi["packed_vit_position_ids"]
-        return (cache.slabs[0].k.data_ptr(), cache.cap, len(cache.lens), lens[0], int(pos[0]), int(pos[-1]), int(gi["packed_text_ids"][0]),
+        # the captured graph bakes in the K / V^T slab addresses of EVERY layer: all of them are part of the key, so a graph can
+        # only be replayed on storage laid out exactly like the one it was captured on (a new cache that happens to reuse the
+        # layer-0 address alone must not match - it would be written through stale addresses for the other layers)
+        slabs = tuple(p for sl in cache.slabs for p in (sl.k.data_ptr(), sl.vt.data_ptr()))
+        return (slabs, cache.cap, len(cache.lens), lens[0], int(pos[0]), int(pos[-1]), int(gi["packed_text_ids"][0]),
                 int(gi["packed_text_ids"][-1]))
 
     def _vit_graph_run(self, key, cache, gi):
@@ -288,14 +292,23 @@ class Bagel(BagelPrep):
 
     # ------------------------------------------------------------------ text generation
     def _sampling_seed(self):
-        """Next 62-bit key for the device-side sampler from a DEDICATED generator seeded with torch.initial_seed(): like the
-        reference's CUDA multinomial (bagel.py:1297-1299) a sampled decode leaves torch's CPU RNG state untouched, so the
-        init noise prepare_vae_latent draws afterwards is what it would have been; torch.manual_seed(s) restarts the stream."""
-        base = torch.initial_seed()
-        if getattr(self, "_sample_gen_base", None) != base:
-            self._sample_gen_base = base
-            self._sample_gen = torch.Generator().manual_seed(base)
-        return int(torch.randint(0, 2 ** 62, (1,), generator=self._sample_gen).item())
+        """Next 62-bit key for the device-side sampler, derived from the CURRENT state of torch's default CPU generator
+        WITHOUT consuming it: the state is copied into a private generator, one draw is taken from the copy, and a counter
+        distinguishes successive calls made under one and the same state.  So, like the reference's CUDA multinomial
+        (bagel.py:1297-1299), a sampled decode leaves torch's CPU RNG untouched (the init noise prepare_vae_latent draws
+        afterwards is what it would have been), and `torch.manual_seed(s)` - also with the SAME s again, the usual
+        per-sample evaluation pattern - restarts the stream: two identical calls each preceded by manual_seed(42) sample
+        identical text."""
+        state = torch.get_rng_state()
+        tag = hash(state.numpy().tobytes())
+        if getattr(self, "_sample_state_tag", None) != tag:
+            self._sample_state_tag, self._sample_calls = tag, 0
+        g = torch.Generator()
+        g.set_state(state)
+        base = int(torch.randint(0, 2 ** 62, (1,), generator=g).item())
+        k = self._sample_calls
+        self._sample_calls += 1
+        return (base + k * 0x9E3779B97F4A7C15) % (2 ** 62)
 
     @torch.no_grad()
     @ops.on_device

@@ -266,11 +266,9 @@ template <int HD, int TQ>
 static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
     constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
     constexpr int lds = 2 * ATTN_PREFILL_NB(HD, TQ) * (2 * KS + DT) * 1024;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[UMV_MAX_DEVICES] = {};
+    if (umv_first_on_device(attr))
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
     dim3 grid((qtiles + 4 * TQ - 1) / (4 * TQ), a.nkv, a.nseg);
     hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ>), grid, dim3(256), lds, s, a, scale_log2e);
     UMV_LAUNCH_CHECK();

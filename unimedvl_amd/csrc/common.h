@@ -99,6 +99,17 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ bf16x8 ldg_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ bf16x8 zero_frag() { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
 
+// hipFuncSetAttribute is per DEVICE: an engine on cuda:1 of the same process needs the dynamic-LDS limit raised there too, so the
+// "already done" flag of a kernel is an array indexed by the current device (true = first call on this device)
+#define UMV_MAX_DEVICES 64
+static inline bool umv_first_on_device(bool* flags) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= UMV_MAX_DEVICES) return true;
+    if (flags[d]) return false;
+    flags[d] = true;
+    return true;
+}
+
 // error plumbing (host side)
 void umv_set_error(const char* fmt, ...);
 #define UMV_CHECK(cond, code, ...)            \

@@ -758,7 +758,11 @@ __global__ __launch_bounds__(256) void decode_step_end_argmax_kernel(int32_t* sl
                                                                      int32_t* ticket, int B, int max_len) {
     __shared__ uint64_t sm[4];
     const int b = blockIdx.x;
-    const int64_t s = step_idx[0];
+    // step_idx[0] is read by every workgroup and advanced by the LAST ticket holder: both sides use relaxed agent-scope atomics (no
+    // C++ data race), and the compiler barrier in front of the ticket keeps the read and the stores that depend on it ahead of the
+    // ticket in program order - a wave issues its memory operations in order, so no workgroup can see the advanced counter.
+    // (A release / acquire pair on the ticket would say the same formally and cost an L2 write-back + invalidate per step.)
+    const int64_t s = __hip_atomic_load(step_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t* row = part + (int64_t)b * n_tiles;
     uint64_t best = 0;
     constexpr int UA = 8;      // all loads of a thread in flight together: one round trip for up to 2048 tiles per pass
@@ -786,9 +790,10 @@ __global__ __launch_bounds__(256) void decode_step_end_argmax_kernel(int32_t* sl
         if (s < max_len) pred_ids[s * B + b] = id;
         if (s + 1 < max_len) in_ids[(s + 1) * B + b] = id;
         slot[b] += 1; pos[b] += 1; kv_len[b] += 1;
+        asm volatile("" ::: "memory");
         const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == B - 1) {
-            step_idx[0] = s + 1;
+            __hip_atomic_store(step_idx, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

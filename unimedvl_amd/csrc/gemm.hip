@@ -1039,11 +1039,10 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024 + BN * 2;   // staging buffers + the tile's bias
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[UMV_MAX_DEVICES] = {};
+    if (umv_first_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
     const int splits = a.k_splits > 1 ? a.k_splits : 1;

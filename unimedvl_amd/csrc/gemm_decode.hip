@@ -362,11 +362,10 @@ static int launch_decode(const umv_gemm_args& a, const umv_decode_layout& L, int
     constexpr int NP = SWIGLU ? 2 : 1;
     size_t lds = (size_t)2 * DG_WAVES * NP * 64 * sizeof(f32x4);
     if (NORM) lds += DG_WAVES * 16 * sizeof(float) + (size_t)KT * 4 * NORM * 16 + DG_WAVES * 64 * 16;   // partials, xl, wl
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[UMV_MAX_DEVICES] = {};
+    if (umv_first_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_decode_kernel<W8, NORM, XREG, SWIGLU, U>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_decode_kernel<W8, NORM, XREG, SWIGLU, U>), dim3(L.G), dim3(DG_WAVES * 64), lds, s, a, L, KT);
     UMV_LAUNCH_CHECK();

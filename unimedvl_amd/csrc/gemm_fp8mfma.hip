@@ -336,11 +336,10 @@ static int launch_tiled8(const umv_gemm8_args& a, int KT, int NTT, hipStream_t s
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr size_t lds = (size_t)NBUF * 2 * (BN / 16 + BM / 16) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[UMV_MAX_DEVICES] = {};
+    if (umv_first_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tiled8_kernel<WN, WM, TN, TM, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-        attr_set = true;
     }
     const int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_tiled8_kernel<WN, WM, TN, TM, NBUF>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks,

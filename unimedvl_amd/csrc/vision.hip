@@ -351,11 +351,10 @@ static int launch_conv(const bf16_t* x, const bf16_t* wp, const bf16_t* bias, co
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[UMV_MAX_DEVICES] = {};
+    if (umv_first_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tiled_kernel<WN, WM, TN, TM, KTS, NBUF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     const int M = geo.B * geo.Hout * geo.Wout;
     const int mblocks = (M + BM - 1) / BM, nblocks = (geo.Cout + BN - 1) / BN;
