@@ -231,9 +231,34 @@ def test_load_from_checkpoint_directory(tmp_path):
     ref = Bagel(cfg, lambda n: sd[n], device="cuda", visual_gen=False)
     want = ref.chat(tok, nt, v.image_transform, [pil], "What abnormality is visible?", max_length=6)
     assert res["answer"] == want
+
+    # ---- the on-disk fast path (packstore.py; the reference's one-time ema_bf16.safetensors conversion,
+    # interactive_vqa_inferencer.py:93-161): the first load wrote the device-ready images, the second reads only them
+    packed = ckpt / "ema_packed_w-bf16_a-bf16_und.safetensors"
+    assert v.load_stats["packed_cache"] == "written" and v.load_stats["from_packed"] == 0 and packed.exists()
+    v2 = VQAInferencer({"model_path": str(ckpt), "max_new_tokens": 6, "do_sample": False})
+    v2.load_model()
+    assert v2.load_stats["packed_cache"] == "hit" and v2.load_stats["built"] == 0 and v2.load_stats["from_packed"] > 10
+    assert v2.infer_single(pil, "What abnormality is visible?")["answer"] == want
+    w1, w2 = v.model.language_model.w, v2.model.language_model.w
+    assert torch.equal(w1.und[1].gate_up.wp, w2.und[1].gate_up.wp) and torch.equal(w1.lm_head.wp, w2.lm_head.wp)
+    # fp8 weights get their own file (e4m3 images + scales stored, nothing re-quantised on the second load)
+    v8 = VQAInferencer({"model_path": str(ckpt), "max_new_tokens": 6, "do_sample": False, "llm_weight_dtype": "fp8"})
+    v8.load_model()
+    assert v8.load_stats["packed_cache"] == "written" and (ckpt / "ema_packed_w-fp8_a-bf16_und.safetensors").exists()
+    a8 = v8.infer_single(pil, "What abnormality is visible?")["answer"]
+    v8b = VQAInferencer({"model_path": str(ckpt), "max_new_tokens": 6, "do_sample": False, "llm_weight_dtype": "fp8"})
+    v8b.load_model()
+    assert v8b.load_stats["packed_cache"] == "hit" and v8b.load_stats["built"] == 0
+    assert torch.equal(v8.model.language_model.w.und[0].qkv.w8, v8b.model.language_model.w.und[0].qkv.w8)
+    assert v8b.infer_single(pil, "What abnormality is visible?")["answer"] == a8
+    # "packed_cache": False never touches the file; a changed source checkpoint invalidates it
+    v3 = VQAInferencer({"model_path": str(ckpt), "packed_cache": False})
+    v3.load_model()
+    assert v3.load_stats["packed_cache"] == "disabled" and v3.load_stats["from_packed"] == 0
     # a shape mismatch in the file is reported by tensor name, not as a kernel fault later
     bad = dict(sd)
     bad["language_model.model.norm.weight"] = torch.zeros(c["hidden"] + 8, dtype=torch.bfloat16)
     save_file({k: t.contiguous() for k, t in bad.items()}, str(ckpt / "ema.safetensors"))
     with pytest.raises(ValueError, match="language_model.model.norm.weight"):
-        VQAInferencer({"model_path": str(ckpt)}).load_model()
+        VQAInferencer({"model_path": str(ckpt)}).load_model()      # (the packed file of the OLD ema.safetensors is not trusted)

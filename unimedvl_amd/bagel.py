@@ -292,23 +292,12 @@ class Bagel(BagelPrep):
 
     # ------------------------------------------------------------------ text generation
     def _sampling_seed(self):
-        """Next 62-bit key for the device-side sampler, derived from the CURRENT state of torch's default CPU generator
-        WITHOUT consuming it: the state is copied into a private generator, one draw is taken from the copy, and a counter
-        distinguishes successive calls made under one and the same state.  So, like the reference's CUDA multinomial
-        (bagel.py:1297-1299), a sampled decode leaves torch's CPU RNG untouched (the init noise prepare_vae_latent draws
-        afterwards is what it would have been), and `torch.manual_seed(s)` - also with the SAME s again, the usual
-        per-sample evaluation pattern - restarts the stream: two identical calls each preceded by manual_seed(42) sample
-        identical text."""
-        state = torch.get_rng_state()
-        tag = hash(state.numpy().tobytes())
-        if getattr(self, "_sample_state_tag", None) != tag:
-            self._sample_state_tag, self._sample_calls = tag, 0
-        g = torch.Generator()
-        g.set_state(state)
-        base = int(torch.randint(0, 2 ** 62, (1,), generator=g).item())
-        k = self._sample_calls
-        self._sample_calls += 1
-        return (base + k * 0x9E3779B97F4A7C15) % (2 ** 62)
+        """Next 62-bit key for the device-side sampler: one draw from the DEVICE's default generator - the generator the
+        reference's multinomial consumes (bagel.py:1297-1299 samples on the GPU).  So torch.manual_seed(s) - which reseeds it -
+        restarts the stream, also with the same s again (two identical calls each preceded by manual_seed(42) sample identical
+        text), successive calls draw new keys, and torch's CPU generator is left untouched (the init noise
+        prepare_vae_latent draws afterwards is what it would have been)."""
+        return int(torch.randint(0, 2 ** 62, (1,), device=self.device).item())
 
     @torch.no_grad()
     @ops.on_device

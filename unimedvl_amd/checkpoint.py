@@ -72,6 +72,14 @@ def checkpoint_getter(model_path, expected_shapes=None, checkpoint_weight_path=N
     return OverlayGetter(SafetensorsGetter(find_weights_file(checkpoint_weight_path, False), expected_shapes), base)
 
 
+def checkpoint_source_files(model_path, checkpoint_weight_path=None, use_model_checkpoint=False):
+    """the safetensors files checkpoint_getter reads (the packed fast-path file is keyed on their names / sizes / mtimes)"""
+    files = [find_weights_file(model_path, use_model_checkpoint)]
+    if checkpoint_weight_path is not None:
+        files.insert(0, find_weights_file(checkpoint_weight_path, False))
+    return files
+
+
 def dict_getter(sd):
     return lambda name: sd[name]
 

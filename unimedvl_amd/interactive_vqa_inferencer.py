@@ -16,7 +16,8 @@ import torch
 from PIL import Image
 
 from .bagel import Bagel
-from .checkpoint import checkpoint_getter
+from . import packstore
+from .checkpoint import checkpoint_getter, checkpoint_source_files
 from .config import UniMedVLConfig
 from .data_utils import add_special_tokens, pil_img2rgb
 from .shapes import all_shapes
@@ -94,7 +95,22 @@ class VQAInferencer:
             cfg.llm_weight_dtype = self.config.get("llm_weight_dtype", "bf16")
             get = checkpoint_getter(model_path, all_shapes(cfg), self.config.get("checkpoint_weight_path"),
                                     self.config["use_model_checkpoint"])
+            # fast path (not a reference key; the counterpart of its one-time ema_bf16.safetensors conversion,
+            # interactive_vqa_inferencer.py:93-161): "packed_cache" (default True) keeps the device-ready weight images in
+            # <model_path>/ema_packed_*.safetensors after the first load and reads them back on every later one
+            t_load = time.time()
+            store = packstore.attach(get, self.config.get("checkpoint_weight_path") or model_path, device, cfg,
+                                     checkpoint_source_files(model_path, self.config.get("checkpoint_weight_path"),
+                                                             self.config["use_model_checkpoint"]),
+                                     enabled=bool(self.config.get("packed_cache", True)), extra_tag="_und")
             model = Bagel(cfg, get, device=device, visual_gen=False, visual_und=True)
+            torch.cuda.synchronize()
+            self.load_stats = {"load_s": round(time.time() - t_load, 3), "packed_cache": store.status, "from_packed": store.hits,
+                               "built": store.misses}
+            t_save = store.save()
+            if t_save is not None:
+                self.load_stats.update(packed_cache=store.status, packed_cache_write_s=round(t_save, 3))
+            print(f"weights: {self.load_stats}")
             tokenizer = load_tokenizer(model_path)
             tokenizer, new_token_ids, _ = add_special_tokens(tokenizer)
         self.model, self.tokenizer, self.new_token_ids = model, tokenizer, new_token_ids

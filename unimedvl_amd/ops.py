@@ -74,6 +74,10 @@ class PackedLinear:
 
     def enable_fp8_mfma(self, keep_bf16=False):
         """Build the fp8-MFMA image from the e4m3 image; the bf16 image of the dequantised weights is dropped unless asked."""
+        if self.w8m is not None:        # already there (e.g. read back from the packed fast-path file)
+            if not keep_bf16:
+                self.wp = None
+            return self
         if self.w8 is None:
             raise _lib.UmvError("enable_fp8_mfma needs fp8 weights (from_weight_fp8 / from_gate_up_fp8)")
         lib = _lib.load()

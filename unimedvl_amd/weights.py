@@ -24,10 +24,32 @@ def _dev(t, device):
     return t.to(device=device, dtype=BF16).contiguous()
 
 
+class _NoStore:
+    """stand-in when the getter carries no packstore.PackStore: build everything"""
+    @staticmethod
+    def linear(key, build):
+        return build()
+
+    @staticmethod
+    def tensor(name, build):
+        return build()
+
+
+def _store(get):
+    return getattr(get, "pack_store", None) or _NoStore
+
+
+def _tensor(get, device, name):
+    """bf16 device tensor `name`: from the packed fast-path file when the getter has one (packstore.py), else from the checkpoint"""
+    return _store(get).tensor(name, lambda: _dev(get(name), device))
+
+
 def _linear(get, device, wname, bname=None, fp8=False):
-    w = _dev(get(wname), device)
-    b = _dev(get(bname), device) if bname else None
-    return ops.PackedLinear.from_weight_fp8(w, b) if fp8 else ops.PackedLinear.from_weight(w, b)
+    def build():
+        w = _dev(get(wname), device)
+        b = _dev(get(bname), device) if bname else None
+        return ops.PackedLinear.from_weight_fp8(w, b) if fp8 else ops.PackedLinear.from_weight(w, b)
+    return _store(get).linear(wname, build)
 
 
 class LLMWeights:
@@ -41,7 +63,7 @@ class LLMWeights:
         if cfg.llm_act_dtype not in ("bf16", "fp8") or (cfg.llm_act_dtype == "fp8" and not fp8):
             raise ValueError("llm_act_dtype must be 'bf16', or 'fp8' together with llm_weight_dtype='fp8'")
         self.act8 = cfg.llm_act_dtype == "fp8"
-        self.embed = _dev(get(p + "embed_tokens.weight"), device)
+        self.embed = _tensor(get, device, p + "embed_tokens.weight")
         self.und, self.gen = [], []
         for l in range(cfg.layers):
             self.und.append(self._layer(get, device, p + f"layers.{l}.", "", fp8))
@@ -51,8 +73,8 @@ class LLMWeights:
                     if lw is not None:
                         for lin in (lw.qkv, lw.o, lw.gate_up, lw.down):
                             lin.enable_fp8_mfma()
-        self.norm = _dev(get(p + "norm.weight"), device)
-        self.norm_gen = _dev(get(p + "norm_moe_gen.weight"), device) if load_gen else None
+        self.norm = _tensor(get, device, p + "norm.weight")
+        self.norm_gen = _tensor(get, device, p + "norm_moe_gen.weight") if load_gen else None
         self.lm_head = _linear(get, device, "language_model.lm_head.weight", fp8=fp8)
         # rotary tables exactly as Qwen2RotaryEmbedding returns them (modeling_qwen2.py:164-184):
         # fp32 outer product, cos/sin, cast to bf16; built on the CPU so the bits match torch's.
@@ -68,20 +90,25 @@ class LLMWeights:
     def _layer(get, device, p, suf, fp8=False):
         lw = LayerWeights()
         a = p + "self_attn."
-        w = torch.cat([_dev(get(a + f"{n}_proj{suf}.weight"), device) for n in "qkv"], 0)
-        b = torch.cat([_dev(get(a + f"{n}_proj{suf}.bias"), device) for n in "qkv"], 0)
-        lw.qkv = ops.PackedLinear.from_weight_fp8(w, b) if fp8 else ops.PackedLinear.from_weight(w, b)
-        del w
+        st = _store(get)
+
+        def build_qkv():
+            w = torch.cat([_dev(get(a + f"{n}_proj{suf}.weight"), device) for n in "qkv"], 0)
+            b = torch.cat([_dev(get(a + f"{n}_proj{suf}.bias"), device) for n in "qkv"], 0)
+            return ops.PackedLinear.from_weight_fp8(w, b) if fp8 else ops.PackedLinear.from_weight(w, b)
+
+        def build_gate_up():
+            g = _dev(get(p + f"mlp{suf}.gate_proj.weight"), device)
+            u = _dev(get(p + f"mlp{suf}.up_proj.weight"), device)
+            return ops.PackedLinear.from_gate_up_fp8(g, u) if fp8 else ops.PackedLinear.from_gate_up(g, u)
+        lw.qkv = st.linear(a + f"qkv_proj{suf}", build_qkv)
         lw.o = _linear(get, device, a + f"o_proj{suf}.weight", fp8=fp8)
-        g = _dev(get(p + f"mlp{suf}.gate_proj.weight"), device)
-        u = _dev(get(p + f"mlp{suf}.up_proj.weight"), device)
-        lw.gate_up = ops.PackedLinear.from_gate_up_fp8(g, u) if fp8 else ops.PackedLinear.from_gate_up(g, u)
-        del g, u
+        lw.gate_up = st.linear(p + f"mlp{suf}.gate_up_proj", build_gate_up)
         lw.down = _linear(get, device, p + f"mlp{suf}.down_proj.weight", fp8=fp8)
-        lw.in_norm = _dev(get(p + f"input_layernorm{suf}.weight"), device)
-        lw.post_norm = _dev(get(p + f"post_attention_layernorm{suf}.weight"), device)
-        lw.q_norm = _dev(get(a + f"q_norm{suf}.weight"), device)
-        lw.k_norm = _dev(get(a + f"k_norm{suf}.weight"), device)
+        lw.in_norm = _tensor(get, device, p + f"input_layernorm{suf}.weight")
+        lw.post_norm = _tensor(get, device, p + f"post_attention_layernorm{suf}.weight")
+        lw.q_norm = _tensor(get, device, a + f"q_norm{suf}.weight")
+        lw.k_norm = _tensor(get, device, a + f"k_norm{suf}.weight")
         return lw
 
     def decode_weight_bytes(self):
@@ -104,22 +131,24 @@ class ViTWeights:
         self.k_pad = (self.k_in + 31) // 32 * 32
         self.patch = _linear(get, device, p + "embeddings.patch_embedding.weight", p + "embeddings.patch_embedding.bias")
         self.patch.K = self.k_pad   # x is zero padded to a 32 multiple; the packed image already is
-        self.pos = _dev(get(p + "embeddings.position_embedding.weight"), device)
+        self.pos = _tensor(get, device, p + "embeddings.position_embedding.weight")
         self.layers = []
         for l in range(cfg.vit_layers):
             q = p + f"encoder.layers.{l}."
             lw = ViTLayer()
-            w = torch.cat([_dev(get(q + f"self_attn.{n}_proj.weight"), device) for n in "qkv"], 0)
-            b = torch.cat([_dev(get(q + f"self_attn.{n}_proj.bias"), device) for n in "qkv"], 0)
-            lw.qkv = ops.PackedLinear.from_weight(w, b)
+            def build_qkv(q=q):
+                w = torch.cat([_dev(get(q + f"self_attn.{n}_proj.weight"), device) for n in "qkv"], 0)
+                b = torch.cat([_dev(get(q + f"self_attn.{n}_proj.bias"), device) for n in "qkv"], 0)
+                return ops.PackedLinear.from_weight(w, b)
+            lw.qkv = _store(get).linear(q + "self_attn.qkv_proj", build_qkv)
             lw.out = _linear(get, device, q + "self_attn.out_proj.weight", q + "self_attn.out_proj.bias")
             lw.fc1 = _linear(get, device, q + "mlp.fc1.weight", q + "mlp.fc1.bias")
             lw.fc2 = _linear(get, device, q + "mlp.fc2.weight", q + "mlp.fc2.bias")
-            lw.ln1_w, lw.ln1_b = _dev(get(q + "layer_norm1.weight"), device), _dev(get(q + "layer_norm1.bias"), device)
-            lw.ln2_w, lw.ln2_b = _dev(get(q + "layer_norm2.weight"), device), _dev(get(q + "layer_norm2.bias"), device)
+            lw.ln1_w, lw.ln1_b = _tensor(get, device, q + "layer_norm1.weight"), _tensor(get, device, q + "layer_norm1.bias")
+            lw.ln2_w, lw.ln2_b = _tensor(get, device, q + "layer_norm2.weight"), _tensor(get, device, q + "layer_norm2.bias")
             self.layers.append(lw)
-        self.post_w = _dev(get(p + "post_layernorm.weight"), device)
-        self.post_b = _dev(get(p + "post_layernorm.bias"), device)
+        self.post_w = _tensor(get, device, p + "post_layernorm.weight")
+        self.post_b = _tensor(get, device, p + "post_layernorm.bias")
 
 
 class GlueWeights:
@@ -129,9 +158,9 @@ class GlueWeights:
         if visual_und:
             self.conn1 = _linear(get, device, "connector.fc1.weight", "connector.fc1.bias")
             self.conn2 = _linear(get, device, "connector.fc2.weight", "connector.fc2.bias")
-            self.vit_pos = _dev(get("vit_pos_embed.pos_embed"), device)
+            self.vit_pos = _tensor(get, device, "vit_pos_embed.pos_embed")
         if visual_gen:
-            self.latent_pos = _dev(get("latent_pos_embed.pos_embed"), device)
+            self.latent_pos = _tensor(get, device, "latent_pos_embed.pos_embed")
             self.time0 = _linear(get, device, "time_embedder.mlp.0.weight", "time_embedder.mlp.0.bias")
             self.time2 = _linear(get, device, "time_embedder.mlp.2.weight", "time_embedder.mlp.2.bias")
             self.vae2llm = _linear(get, device, "vae2llm.weight", "vae2llm.bias")
