@@ -341,6 +341,54 @@ def run_mixed(model, cfg, dev, rank, world, dist, n_vqa=8, n_t2i=4, new_tokens=1
             "includes": "VQA ViT + prefill, decode rounds of 8 graph steps, 2 Euler steps per round, VAE decode of the image group"}
 
 
+def run_load_path(cfg, dev, layers=2):
+    """The load path (the reference: "may take 5-10 minutes", interactive_vqa_inferencer.py:196) on a
+    synthetic FULL-WIDTH checkpoint of `layers` LLM layers + the whole ViT written to the box's scratch disk: first load =
+    safetensors -> bf16 -> device -> MFMA re-tiling (+ writing the packed fast-path file), second load = the packed file read
+    straight onto the device (packstore.py).  Reported per GB so that it scales to the 29 GB of the full model."""
+    import shutil
+    import tempfile
+    from safetensors.torch import save_file
+    from unimedvl_amd import packstore, shapes
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.checkpoint import checkpoint_getter
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.weights import random_getter
+    c2 = UniMedVLConfig.from_dict(cfg.to_dict())
+    c2.layers = layers
+    d = tempfile.mkdtemp(prefix="umv_load_")
+    try:
+        get = random_getter(c2, dev, seed=99)
+        names = [n for n in shapes.all_shapes(c2) if "_moe_gen" not in n and not any(k in n for k in ("latent_pos", "time_embedder", "vae2llm", "llm2vae"))]
+        sd = {n: get(n).cpu().contiguous() for n in names}
+        nbytes = sum(t.numel() * t.element_size() for t in sd.values())
+        t0 = time.time()
+        save_file(sd, os.path.join(d, "ema.safetensors"))
+        t_ckpt = time.time() - t0
+        del sd
+        out = {"checkpoint_GB": round(nbytes / 1e9, 2), "layers": layers, "write_checkpoint_s": round(t_ckpt, 2)}
+        for tag in ("first_load", "second_load"):
+            g = checkpoint_getter(d, None)
+            t0 = time.time()
+            store = packstore.attach(g, d, dev, c2, [os.path.join(d, "ema.safetensors")], extra_tag="_und")
+            m = Bagel(c2, g, device=dev, visual_gen=False, visual_und=True)
+            torch.cuda.synchronize()
+            out[tag + "_s"] = round(time.time() - t0, 2)
+            out[tag + "_GB_per_s"] = round(nbytes / 1e9 / max(time.time() - t0, 1e-6), 2)
+            out[tag + "_packed_cache"] = store.status
+            ts = store.save()
+            if ts is not None:
+                out["packed_write_s"] = round(ts, 2)
+            del m, g, store
+            torch.cuda.empty_cache()
+        out["full_model_estimate_s"] = {"first_load": round(29.0 / max(out["first_load_GB_per_s"], 1e-6), 1),
+                                        "later_loads": round(29.0 / max(out["second_load_GB_per_s"], 1e-6), 1),
+                                        "note": "29 GB of bf16 images (both experts) at the measured GB/s of this box's scratch disk / page cache"}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def run_t2i(model, cfg, dev, rank, world, dist, batch=4, hw=256, prompt_len=128, num_timesteps=50):
     """BASELINE.json configs[2]: text-to-image, 50 diffusion steps, 256x256, batch 4 per GPU, the reference
     defaults of InterleaveInferencer.gen_image (cfg_text 4.0, cfg_img 1.5, interval (0.4,1], shift 3.0, global
@@ -416,6 +464,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
     ap.add_argument("--config", default="full", choices=["full", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-load-path", action="store_true", help="skip the checkpoint load-path leg")
     ap.add_argument("--no-vit", action="store_true", help="skip the ViT encode leg (profiling runs of the decode step)")
     ap.add_argument("--strict-profile", action="store_true",
                     help="fail instead of reporting traffic: null when profiles/roofline_profile_latest.json was not measured on this library")
@@ -853,6 +902,11 @@ def main():
                 out["mixed_fp8"] = {"failed": f"{type(e).__name__}: {e}"}
         del model8, l8
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.config == "full" and not args.no_load_path:
+        try:
+            out["load_path"] = run_load_path(cfg, dev)
+        except Exception as e:      # an extra leg must never take the bench line down
+            out["load_path"] = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
         try:
             out["cpu_baseline"] = cpu_baseline(B, ctx, cfg.layers)

@@ -10,7 +10,7 @@
 set -e
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--no-cpu-baseline --no-t2i --no-fp8 --no-report --no-vit"
+ARGS="--no-cpu-baseline --no-t2i --no-fp8 --no-report --no-vit --no-load-path"
 mkdir -p gpurun_out/$TAG/trace gpurun_out/$TAG/FETCH_SIZE gpurun_out/$TAG/WRITE_SIZE
 rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/trace -o bench -- python bench.py $ARGS --steps 512 --warmup 8 > gpurun_out/$TAG/trace/bench.log 2>&1 || true
 grep '^{' gpurun_out/$TAG/trace/bench.log > gpurun_out/${TAG}_decode_line_under_rocprof.json || true
