@@ -11,6 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "unimedvl_hip.h")
+EXP_HEADER = os.path.join(ROOT, "include", "unimedvl_hip_experimental.h")
 
 PAIRS = {   # C struct -> ctypes class name in unimedvl_amd._lib
     "umv_gemm_args": "GemmArgs",
@@ -25,7 +26,7 @@ PAIRS = {   # C struct -> ctypes class name in unimedvl_amd._lib
 
 def _c_fields(struct):
     """Field names of `typedef struct { ... } <struct>;` in declaration order (comments stripped, `a, b;` lists split)."""
-    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read() + open(EXP_HEADER).read(), flags=re.S)
     m = re.search(r"typedef struct\s*\{([^{}]*)\}\s*" + struct + r"\s*;", src)
     assert m, struct
     names = []
@@ -41,7 +42,7 @@ def _c_fields(struct):
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
 def test_ctypes_structs_match_the_header(tmp_path):
     from unimedvl_amd import _lib
-    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', f'#include "{EXP_HEADER}"', "int main(void) {"]
     for cs in PAIRS:
         lines.append(f'  printf("{cs} size %zu\\n", sizeof({cs}));')
         for f in _c_fields(cs):
@@ -69,14 +70,19 @@ def test_ctypes_signatures_match_the_header():
     """Every function the header declares is bound in _lib._SIGS with the same number of parameters, pointer parameters as
     pointers / void*, 64-bit integers as 64-bit, floats as floats."""
     from unimedvl_amd import _lib
-    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    _check_signatures(HEADER, _lib._SIGS, 38)
+    _check_signatures(EXP_HEADER, _lib._EXP_SIGS, 8)
+
+
+def _check_signatures(header, sigs, at_least):
+    src = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
     src = re.sub(r"typedef struct\s*\{[^{}]*\}\s*\w+\s*;", "", src)
     decls = re.findall(r"\b(?:int|size_t|const char\s*\*)\s+(umv_\w+)\s*\(([^()]*)\)\s*;", src)
-    assert len(decls) >= 40
+    assert len(decls) >= at_least, len(decls)
     for name, params in decls:
-        assert name in _lib._SIGS, f"{name} is declared in the header but not bound"
+        assert name in sigs, f"{name} is declared in the header but not bound"
         plist = [p.strip() for p in params.split(",")] if params.strip() not in ("", "void") else []
-        argtypes = _lib._SIGS[name][1]
+        argtypes = sigs[name][1]
         assert len(argtypes) == len(plist), f"{name}: {len(plist)} parameters in the header, {len(argtypes)} in _SIGS"
         for p, t in zip(plist, argtypes):
             if "*" in p or "umv_stream_t" in p:
@@ -87,4 +93,4 @@ def test_ctypes_signatures_match_the_header():
                 assert t is ctypes.c_float, f"{name}: {p} vs {t}"
             else:
                 assert t in (ctypes.c_int, ctypes.c_uint, ctypes.c_bool), f"{name}: {p} vs {t}"
-    assert set(_lib._SIGS) == {n for n, _ in decls}, set(_lib._SIGS) ^ {n for n, _ in decls}
+    assert set(sigs) == {n for n, _ in decls}, set(sigs) ^ {n for n, _ in decls}

@@ -86,16 +86,11 @@ class DeOp(C.Structure):
 
 
 _SIGS = {
-    "umv_decode_engine_counter_words": (C.c_size_t, []),
-    "umv_decode_engine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "umv_decode_engine_traced": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                           C.c_void_p]),
     "umv_packed_weight_fp8_mfma_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "umv_repack_weight_fp8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_quantize_act_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int, C.c_int, C.c_void_p]),
     "umv_gemm_fp8a8w": (C.c_int, [C.POINTER(Gemm8Args), C.c_void_p]),
-    "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
     "umv_gemm_tile_config": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "umv_attn_prefill_tq": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "umv_version": (C.c_int, []),
@@ -110,11 +105,6 @@ _SIGS = {
     "umv_quantize_pack_weight_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_int, C.c_void_p]),
     "umv_gemm_fp8w": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
-    "umv_decode_layout_for": (C.c_int, [C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
-    "umv_decode_image_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
-    "umv_repack_weight_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                           C.POINTER(DecodeLayout), C.c_void_p]),
-    "umv_gemm_decode": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(DecodeLayout), C.c_int, C.c_void_p]),
     "umv_residual_rmsnorm_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_float, C.c_void_p]),
     "umv_rmsnorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -137,7 +127,6 @@ _SIGS = {
                                       C.c_int, C.c_void_p]),
     "umv_decode_step_end_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "umv_prefetch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "umv_timestep_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_cfg_renorm_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -155,7 +144,25 @@ _SIGS = {
                                              C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
 }
 
+# libunimedvl_hip_experimental.so (include/unimedvl_hip_experimental.h): measured, not adopted; loaded only by its tests / tools
+_EXP_SIGS = {
+    "umv_exp_last_error": (C.c_char_p, []),
+    "umv_decode_engine_counter_words": (C.c_size_t, []),
+    "umv_decode_engine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "umv_decode_engine_traced": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
+    "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
+    "umv_decode_layout_for": (C.c_int, [C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
+    "umv_decode_image_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
+    "umv_repack_weight_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(DecodeLayout), C.c_void_p]),
+    "umv_gemm_decode": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(DecodeLayout), C.c_int, C.c_void_p]),
+    "umv_prefetch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+EXP_LIB_PATH = os.environ.get("UMV_EXP_LIB_PATH") or os.path.join(HERE, "lib", "libunimedvl_hip_experimental.so")
 _lib = None
+_exp_lib = None
 
 
 class UmvError(RuntimeError):
@@ -184,8 +191,35 @@ def load():
     return lib
 
 
+def load_experimental():
+    """The experimental library (kernels kept with their tests but not on the product path); raises if it is missing."""
+    global _exp_lib
+    if _exp_lib is not None:
+        return _exp_lib
+    load()      # torch's HIP runtime first, as for the product library
+    if not os.path.exists(EXP_LIB_PATH):
+        raise UmvError(f"{EXP_LIB_PATH} not found: build it with `python -m unimedvl_amd.build`")
+    lib = C.CDLL(EXP_LIB_PATH)
+    for name, (res, args) in _EXP_SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _exp_lib = lib
+    return lib
+
+
 def declared_symbols():
     return list(_SIGS.keys())
+
+
+def declared_experimental_symbols():
+    return list(_EXP_SIGS.keys())
+
+
+def check_exp(rc, what):
+    if rc != 0:
+        msg = load_experimental().umv_exp_last_error().decode()
+        raise UmvError(f"{what} failed (rc={rc}): {msg}")
 
 
 def check(rc, what):

@@ -19,7 +19,8 @@
 #include <type_traits>
 
 #include "common.h"
-#include "../../include/unimedvl_hip.h"
+#include "attention_combine.h"
+#include "../../include/unimedvl_hip_experimental.h"
 
 __device__ __forceinline__ bf16x8 adec_mask_keys(bf16x8 v, int nvalid) {
     bf16x8 o;
@@ -317,8 +318,6 @@ static void adec_launch(const umv_attn_decode_args& a, float scale_log2e, hipStr
     hipLaunchKernelGGL((attn_decode_fused_kernel<NS>), dim3(1, a.nkv * a.nsplit, a.nseg), dim3(64), 0, s, a, scale_log2e);
 }
 
-int umv_attn_combine_launch(const float* ws, uint16_t* out, const int32_t* cu_q, int nseg, int nq, int hd, int nsplit, int64_t rows,
-                            hipStream_t s);
 
 extern "C" int umv_attn_decode_fused(const umv_attn_decode_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap, UMV_ERR_ARG, "attn_decode_fused: null args");

@@ -166,7 +166,7 @@ class DecodeLinear:
     __slots__ = ("wd", "scale", "bias", "N", "K", "swiglu", "fp8", "layout")
 
     def __init__(self, lin, n_cus=None):
-        lib = _lib.load()
+        lib = _lib.load_experimental()
         dev = (lin.w8 if lin.w8 is not None else lin.wp).device
         if n_cus is None:
             n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -176,13 +176,13 @@ class DecodeLinear:
         self.fp8 = lin.w8 is not None
         rows = lin.N // 2 if lin.swiglu else lin.N
         self.layout = _lib.DecodeLayout()
-        check(lib.umv_decode_layout_for(rows, n_cus, C.byref(self.layout)), "umv_decode_layout_for")
+        _lib.check_exp(lib.umv_decode_layout_for(rows, n_cus, C.byref(self.layout)), "umv_decode_layout_for")
         nbytes = lib.umv_decode_image_bytes(lin.K, int(lin.swiglu), int(self.fp8), C.byref(self.layout))
         self.wd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         L = self.layout
         self.scale = torch.empty(L.G * L.tpw * (2 if lin.swiglu else 1) * 16, dtype=torch.float32, device=dev) if self.fp8 else None
         src = lin.w8 if self.fp8 else lin.wp
-        check(lib.umv_repack_weight_decode(_p(src), _p(lin.scale) if self.fp8 else None, _p(self.wd), _p(self.scale), rows, lin.K,
+        _lib.check_exp(lib.umv_repack_weight_decode(_p(src), _p(lin.scale) if self.fp8 else None, _p(self.wd), _p(self.scale), rows, lin.K,
                                            int(lin.swiglu), int(self.fp8), C.byref(self.layout), _stream()), "umv_repack_weight_decode")
 
     def nbytes(self):
@@ -192,7 +192,7 @@ class DecodeLinear:
 def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_bias=True, norm_w=None, norm_eps=1e-6):
     """out = epilogue(x @ W^T) for M <= 16 rows from a DecodeLinear; norm_w fuses Qwen2RMSNorm(x) * norm_w (K <= 4096).
     Bit-identical to gemm() on the same weight."""
-    lib = _lib.load()
+    lib = _lib.load_experimental()
     _req(x, BF16, "x")
     assert x.stride(-1) == 1
     M = x.shape[0] if M is None else M
@@ -217,7 +217,7 @@ def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_b
         M=M, N=dlin.N, K=dlin.K, epilogue=flags,
         norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=0,
         w_scale=dlin.scale.data_ptr() if dlin.fp8 else None)
-    check(lib.umv_gemm_decode(C.byref(a), C.byref(dlin.layout), int(dlin.fp8), _stream()), "umv_gemm_decode")
+    _lib.check_exp(lib.umv_gemm_decode(C.byref(a), C.byref(dlin.layout), int(dlin.fp8), _stream()), "umv_gemm_decode")
     return out
 
 
@@ -528,7 +528,7 @@ def attn_decode_fused(qkv, out, slab, cu_q, kv_len, tok_pos, nq, nkv, hd, eps, q
                       workspace=None, partials=None, bias=None):
     """One decode step: q/k norm + RoPE + KV append + attention over kv_len keys, from the raw fused QKV rows (`qkv` bf16)
     or from the fp32 partial sums [n_splits, B, (nq+2nkv)*hd] of a split-K QKV GEMM (`partials`, + `bias`)."""
-    lib = _lib.load()
+    lib = _lib.load_experimental()
     extra = {}
     if partials is not None:
         _req(partials, torch.float32, "partials")
@@ -544,7 +544,7 @@ def attn_decode_fused(qkv, out, slab, cu_q, kv_len, tok_pos, nq, nkv, hd, eps, q
         tok_pos=tok_pos.data_ptr(), q_norm_w=q_norm.data_ptr(), k_norm_w=k_norm.data_ptr(), cos_tab=cos_tab.data_ptr(),
         sin_tab=sin_tab.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
         eps=eps, nsplit=nsplit, workspace=None if workspace is None else workspace.data_ptr(), **extra, **slab.strides())
-    check(lib.umv_attn_decode_fused(C.byref(a), _stream()), "umv_attn_decode_fused")
+    _lib.check_exp(lib.umv_attn_decode_fused(C.byref(a), _stream()), "umv_attn_decode_fused")
     return out
 
 
@@ -601,10 +601,10 @@ def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img
 
 def prefetch(t, nbytes=None, offset=0, blocks=128, stream=None):
     """Pull `nbytes` of tensor `t` (from byte `offset`) into L2 / Infinity Cache on `stream` (default: current)."""
-    lib = _lib.load()
+    lib = _lib.load_experimental()
     total = t.numel() * t.element_size()
     nbytes = total - offset if nbytes is None else min(nbytes, total - offset)
     if nbytes <= 0:
         return
     st = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
-    check(lib.umv_prefetch(C.c_void_p(t.data_ptr() + offset), nbytes, blocks, None, st), "umv_prefetch")
+    _lib.check_exp(lib.umv_prefetch(C.c_void_p(t.data_ptr() + offset), nbytes, blocks, None, st), "umv_prefetch")
