@@ -59,7 +59,7 @@ def test_gemm_decode_layouts_for_model_shapes():
     ops = _ops()
     from unimedvl_amd import _lib
     import ctypes as C
-    lib = _lib.load()
+    lib = _lib.load_experimental()
     want = {4608: (18, 9, 2), 3584: (14, 14, 1), 18944: (74, 15, 5), 152064: (594, None, None)}
     for rows, (c, th, tpw) in want.items():
         L = _lib.DecodeLayout()

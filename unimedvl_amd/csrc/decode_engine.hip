@@ -143,6 +143,15 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
     char* xs = smem + DE_RED_BYTES;
     char* nws = xs + DE_XS_BYTES;
     float* misc = reinterpret_cast<float*>(nws + DE_NW_BYTES);   // [0..7] rstd per row
+    {   // the op table is read field by field with scalar loads: touch every 64-byte line of it once, all loads in flight together,
+        // so that none of the later reads is a cold scalar-cache miss under a saturated memory system (5.5 us at op 0 otherwise)
+        const __attribute__((address_space(4))) int* tbl = (const __attribute__((address_space(4))) int*)(uintptr_t)ops_g;
+        const int nline = (nops * (int)sizeof(umv_de_op) + 63) / 64;
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) acc += tbl[(i < nline ? i : 0) * 16];
+        asm volatile("" ::"s"(acc));
+    }
 
     if (wave < DE_SW) {
         // =========================================================================== streaming wave
@@ -158,6 +167,23 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
         C.op = 0; C.t = C.t1 = C.nk = 0; C.tstride = 0; C.lane_base = nullptr;
         de_iter_seek(C, ops, nops, cu, G, wave, lane);
         P = C;
+        // The first op of the launch, when its x was complete before the launch and needs no norm (o_proj): every streaming wave
+        // fetches its OWN slice of x - requested ahead of the ring fills, so it arrives first - instead of waiting for the
+        // service waves (4 us at launch start, with nothing to hide behind).
+        bool self_x = false;
+        bf16x8 xv0[DE_XK];
+        if (C.op < nops) {
+            const auto& op0 = ops[C.op];
+            self_x = op0.wait_cnt == nullptr && op0.norm_w == nullptr;
+            if (self_x) {
+                const DeShare S0 = de_share(op0, cu, G);
+                const int nk0 = de_slice_nk(S0, wave);
+                const bool ok0 = r < DE_MROWS && r < M;
+                const uint16_t* xr = op0.x + (int64_t)(ok0 ? r : 0) * op0.ldx + (int64_t)(S0.kbase + wave * S0.kt_per) * 32 + g * 8;
+#pragma unroll
+                for (int kk = 0; kk < DE_XK; ++kk) xv0[kk] = (kk < nk0 && ok0) ? ldg_frag(xr + kk * 32) : zero_frag();
+            }
+        }
         bf16x8 FA[DE_XK], FB[DE_XK];
         auto fill = [&](bf16x8(&F)[DE_XK]) {       // the run under the loader cursor -> F, cursor to the next run
             const bool pv = P.op < nops;
@@ -169,9 +195,13 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
             if (pv) de_iter_next(P, ops, nops, cu, G, wave, lane);
         };
         fill(FA);
-        fill(FB);
         const bool rowok = r < DE_MROWS;
         const char* xlane = xs + ((wave * DE_XK * 4 + g) * DE_MROWS + (rowok ? r : 0)) * 16;
+        if (self_x && rowok) {          // (between the fills: x + one frame in registers, not x + two)
+#pragma unroll
+            for (int kk = 0; kk < DE_XK; ++kk) *reinterpret_cast<bf16x8*>(const_cast<char*>(xlane) + kk * (4 * DE_MROWS * 16)) = xv0[kk];
+        }
+        fill(FB);
         int unit_no = 0;      // tiles finished by this workgroup: red double buffer
         int cur_op = -1;
         int pair = 0, t0 = 0;
@@ -182,8 +212,8 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
                 const auto& op = ops[cur_op];
                 pair = op.pair;
                 t0 = C.t;
-                if (op.wait_cnt) __builtin_amdgcn_s_barrier();                          // B0: the lead service wave saw the producers
-                if (op.norm_w) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // raw x staged; scale known
+                if (op.wait_cnt || (op.norm_w && op.ss_in)) __builtin_amdgcn_s_barrier();   // B0: the lead service wave saw the producers
+                if (op.norm_w && !op.ss_in) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // (fallback: raw x staged; scale known)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                                           // B1: x is ready in LDS
             }
@@ -227,6 +257,7 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
     const int sv = wave - DE_SW;
     const int r8 = lane & 7;
     int unit_no = 0;
+    bool first_gemm = true;
     int nev = 0;
     auto stamp = [&]() {       // tuning only: the lead's timeline (s_memtime) into trace[cu][64]
         if (trace && sv == 0 && nev < 64) {
@@ -253,7 +284,7 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
                     __hip_atomic_store(err, 0xDE000000u | (uint32_t)(cu & 0xFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
     };
@@ -315,87 +346,136 @@ __global__ __launch_bounds__(DE_THREADS) void decode_engine_kernel(const umv_de_
         if (S.t0 >= S.t1) { stamp(); stamp(); stamp(); stamp(); continue; }
         const bool dep = op.wait_cnt != nullptr;
         stamp();      // x (and ss_in) are produced inside this launch
-        // (a) the norm weights do not depend on anybody: stage them first.  [k-tile of the workgroup's range][g] 16 bytes
-        if (op.norm_w) {
-            const int nslots = S.nkt * 4;
-            for (int q0 = sv * 64; q0 < nslots; q0 += 64 * DE_NSV) {
-                const int q = q0 + lane;
-                const char* src = q < nslots ? reinterpret_cast<const char*>(op.norm_w + ((int64_t)S.kbase * 32 + q * 8)) : reinterpret_cast<const char*>(zeros);
-                __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(nws + q0 * 16), 16, 0, 0);
-            }
-        }
-        // (b) the producers of x
-        if (dep) {
-            if (sv == 0) poll(op.wait_cnt, op.wait_mode ? S.kg : -1, op.wait_target);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                  // B0: the inputs of this op are visible
-        }
-        stamp();
-        // (c) the RMSNorm scale of every row from the producers' partial sums of squares, summed in a fixed order; all loads
-        //     in flight at once and AHEAD of the x copy (loads return in order: behind it they would wait for all of x)
-        float ss = 0.f;
+        const bool fast_norm = op.norm_w && op.ss_in;      // the producers published their rows' sums of squares
+        const bool self_x = first_gemm && !dep && !op.norm_w; // the streaming waves copy x themselves (first op of the launch)
+        first_gemm = false;
         const int c8 = lane >> 3;
-        if (sv == 0 && op.norm_w && op.ss_in) {
-            float sv_[DE_SS_PER_LANE];
-#pragma unroll
-            for (int i = 0; i < DE_SS_PER_LANE; ++i)
-                sv_[i] = (c8 + i * 8 < op.ss_n) ? __uint_as_float(de_ld_relaxed(reinterpret_cast<const uint32_t*>(op.ss_in + (c8 + i * 8) * DE_MROWS + r8))) : 0.f;
-#pragma unroll
-            for (int i = 0; i < DE_SS_PER_LANE; ++i) ss += sv_[i];
-        }
-        // (d) x rows -> LDS, already as the B fragments of every wave slice: slot ((w*14 + kk)*4 + g)*8 + r
-        if constexpr (!(DBG & 8)) {
-            const int pair_l = lane >> 5, gq = (lane >> 3) & 3;
-            for (int i = sv; i < DE_SW * DE_XK / 2; i += DE_NSV) {
-                // skip instructions whose two (w, kk) pairs are both beyond their slices (wave-uniform)
-                const int w0 = (i * 2) / DE_XK, kk0 = (i * 2) - w0 * DE_XK;
-                const int w1 = (i * 2 + 1) / DE_XK, kk1 = (i * 2 + 1) - w1 * DE_XK;
-                if (kk0 >= de_slice_nk(S, w0) && kk1 >= de_slice_nk(S, w1)) continue;
-                const int w = pair_l ? w1 : w0, kk = pair_l ? kk1 : kk0;
-                const int kb = min(S.nkt, w * S.kt_per), ke = min(S.nkt, kb + S.kt_per);
-                const bool ok = (kb + kk < ke) && r8 < M;
-                const char* src = ok ? reinterpret_cast<const char*>(op.x + (int64_t)r8 * op.ldx + (int64_t)(S.kbase + kb + kk) * 32 + gq * 8)
-                                     : reinterpret_cast<const char*>(zeros);
-                if (dep) __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(xs + i * 1024), 16, 0, 16 /* sc1 */);
-                else __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(xs + i * 1024), 16, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (op.norm_w) {
-            __builtin_amdgcn_s_barrier();                   // raw x and the norm weights are in LDS (every service wave copied a part)
-            if (sv == 0) {
-                if (!op.ss_in && !(DBG & 16)) {             // x was complete before the launch: square the staged rows
-#pragma unroll 8
-                    for (int q = c8; q < DE_SW * DE_XK * 4; q += 8) {
-                        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + (q * DE_MROWS + r8) * 16);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float f = bf2f((bf16_t)v[j]);
-                            ss += f * f;
-                        }
-                    }
+        constexpr int SLOTS = DE_SW * DE_XK * 4 * DE_MROWS / (64 * DE_NSV);     // 16-byte x slots per lane and service wave (14)
+        if (fast_norm) {
+            // ---- Qwen2RMSNorm on the way in, without a round trip through LDS: every service wave takes a quarter of the x slots
+            //      (slot u = ((slice*14 + kk)*4 + g)*8 + row), fetches the norm weights of its slots BEFORE it waits for the
+            //      producers (they depend on nobody), then - one batch, one memory round trip - the producers' sums of squares and
+            //      its x slots with sc1 loads, derives the scale of its lanes' rows, normalises in registers and writes LDS once.
+            {   // norm weights -> LDS [k-tile of the workgroup's range][g], every service wave a part; they are all there after B0
+                const int nslots = S.nkt * 4;
+                for (int q0 = sv * 64; q0 < nslots; q0 += 64 * DE_NSV) {
+                    const int q = q0 + lane;
+                    const char* src = q < nslots ? reinterpret_cast<const char*>(op.norm_w + ((int64_t)S.kbase * 32 + q * 8)) : reinterpret_cast<const char*>(zeros);
+                    __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(nws + q0 * 16), 16, 0, 0);
                 }
-                ss += __shfl_xor(ss, 8, 64);
-                ss += __shfl_xor(ss, 16, 64);
-                ss += __shfl_xor(ss, 32, 64);
-                if (lane < DE_MROWS) misc[lane] = rsqrt_ieee(ss / (float)(op.KT * 32) + op.norm_eps);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                   // the scale of every row is known
-            // Qwen2RMSNorm in place, two bf16 roundings (modeling_qwen2.py:89-94): x <- bf16(w * bf16(x * rstd)); 16-byte slot
-            // u = ((slice*14 + kk)*4 + g)*8 + row, a quarter of the slots per service wave
-            const float rstd = misc[r8];
-#pragma unroll 2
-            for (int it = 0; it < DE_SW * DE_XK * 4 * DE_MROWS / (64 * DE_NSV); ++it) {
-                const int u = (sv * (DE_SW * DE_XK * 4 * DE_MROWS / (64 * DE_NSV)) + it) * 64 + lane;
+            auto slot_src = [&](int it) -> const uint16_t* {
+                const int u = (sv * SLOTS + it) * 64 + lane;
                 const int chunk = u >> 3;
                 const int w = chunk / (DE_XK * 4), rem = chunk - w * (DE_XK * 4);
                 const int kk = rem >> 2, gq = rem & 3;
+                const int kb = min(S.nkt, w * S.kt_per), ke = min(S.nkt, kb + S.kt_per);
+                const bool ok = (kb + kk < ke) && r8 < M;
+                return ok ? op.x + (int64_t)r8 * op.ldx + (int64_t)(S.kbase + kb + kk) * 32 + gq * 8 : zeros;
+            };
+            if (sv == 0 && dep) poll(op.wait_cnt, op.wait_mode ? S.kg : -1, op.wait_target);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // B0: the inputs of this op are visible (and the norm weights in LDS)
+            stamp();
+            float sq[DE_SS_PER_LANE];
+#pragma unroll
+            for (int i = 0; i < DE_SS_PER_LANE; ++i)
+                sq[i] = (c8 + i * 8 < op.ss_n) ? __uint_as_float(de_ld_relaxed(reinterpret_cast<const uint32_t*>(op.ss_in + (c8 + i * 8) * DE_MROWS + r8))) : 0.f;
+            // x slots of this wave: LDS-DMA (sc1: the rows were published by other workgroups) into its own, lane-linear part of xs
+#pragma unroll
+            for (int it = 0; it < SLOTS; ++it)
+                __builtin_amdgcn_global_load_lds((const void*)slot_src(it), (de_lds_ptr_t)(xs + (sv * SLOTS + it) * 1024), 16, 0, 16 /* sc1 */);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < DE_SS_PER_LANE; ++i) ss += sq[i];
+            ss += __shfl_xor(ss, 8, 64);
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rstd = rsqrt_ieee(ss / (float)(op.KT * 32) + op.norm_eps);       // of row r8 = lane & 7 = the row of this lane's slots
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 2
+            for (int it = 0; it < SLOTS; ++it) {
+                const int u = (sv * SLOTS + it) * 64 + lane;
+                const int chunk = u >> 3;
+                const int w = chunk / (DE_XK * 4), rem = chunk - w * (DE_XK * 4);
+                const bf16x8 nw = *reinterpret_cast<const bf16x8*>(nws + ((w * S.kt_per + (rem >> 2)) * 4 + (rem & 3)) * 16);
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + u * 16);
-                const bf16x8 nw = *reinterpret_cast<const bf16x8*>(nws + ((w * S.kt_per + kk) * 4 + gq) * 16);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)nw[j]) * rbf(bf2f((bf16_t)v[j]) * rstd));
                 *reinterpret_cast<bf16x8*>(xs + u * 16) = v;
+            }
+        } else {
+            // (a) the norm weights do not depend on anybody: stage them first.  [k-tile of the workgroup's range][g] 16 bytes
+            if (op.norm_w) {
+                const int nslots = S.nkt * 4;
+                for (int q0 = sv * 64; q0 < nslots; q0 += 64 * DE_NSV) {
+                    const int q = q0 + lane;
+                    const char* src = q < nslots ? reinterpret_cast<const char*>(op.norm_w + ((int64_t)S.kbase * 32 + q * 8)) : reinterpret_cast<const char*>(zeros);
+                    __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(nws + q0 * 16), 16, 0, 0);
+                }
+            }
+            // (b) the producers of x
+            if (dep) {
+                if (sv == 0) poll(op.wait_cnt, op.wait_mode ? S.kg : -1, op.wait_target);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // B0: the inputs of this op are visible
+            }
+            stamp();
+            // (c) x rows -> LDS, already as the B fragments of every wave slice: slot ((w*14 + kk)*4 + g)*8 + r
+            if (!self_x && !(DBG & 8)) {
+                const int pair_l = lane >> 5, gq = (lane >> 3) & 3;
+                for (int i = sv; i < DE_SW * DE_XK / 2; i += DE_NSV) {
+                    // skip instructions whose two (w, kk) pairs are both beyond their slices (wave-uniform)
+                    const int w0 = (i * 2) / DE_XK, kk0 = (i * 2) - w0 * DE_XK;
+                    const int w1 = (i * 2 + 1) / DE_XK, kk1 = (i * 2 + 1) - w1 * DE_XK;
+                    if (kk0 >= de_slice_nk(S, w0) && kk1 >= de_slice_nk(S, w1)) continue;
+                    const int w = pair_l ? w1 : w0, kk = pair_l ? kk1 : kk0;
+                    const int kb = min(S.nkt, w * S.kt_per), ke = min(S.nkt, kb + S.kt_per);
+                    const bool ok = (kb + kk < ke) && r8 < M;
+                    const char* src = ok ? reinterpret_cast<const char*>(op.x + (int64_t)r8 * op.ldx + (int64_t)(S.kbase + kb + kk) * 32 + gq * 8)
+                                         : reinterpret_cast<const char*>(zeros);
+                    if (dep) __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(xs + i * 1024), 16, 0, 16 /* sc1 */);
+                    else __builtin_amdgcn_global_load_lds((const void*)src, (de_lds_ptr_t)(xs + i * 1024), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (op.norm_w) {      // fallback: x was complete before the launch and nobody published its sums of squares
+                __builtin_amdgcn_s_barrier();                   // raw x and the norm weights are in LDS (every service wave copied a part)
+                float ss = 0.f;
+                if (sv == 0) {
+                    if (!(DBG & 16)) {
+#pragma unroll 8
+                        for (int q = c8; q < DE_SW * DE_XK * 4; q += 8) {
+                            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + (q * DE_MROWS + r8) * 16);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float f = bf2f((bf16_t)v[j]);
+                                ss += f * f;
+                            }
+                        }
+                    }
+                    ss += __shfl_xor(ss, 8, 64);
+                    ss += __shfl_xor(ss, 16, 64);
+                    ss += __shfl_xor(ss, 32, 64);
+                    if (lane < DE_MROWS) misc[lane] = rsqrt_ieee(ss / (float)(op.KT * 32) + op.norm_eps);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // the scale of every row is known
+                // Qwen2RMSNorm in place, two bf16 roundings (modeling_qwen2.py:89-94): x <- bf16(w * bf16(x * rstd))
+                const float rstd = misc[r8];
+#pragma unroll 2
+                for (int it = 0; it < SLOTS; ++it) {
+                    const int u = (sv * SLOTS + it) * 64 + lane;
+                    const int chunk = u >> 3;
+                    const int w = chunk / (DE_XK * 4), rem = chunk - w * (DE_XK * 4);
+                    const int kk = rem >> 2, gq = rem & 3;
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + u * 16);
+                    const bf16x8 nw = *reinterpret_cast<const bf16x8*>(nws + ((w * S.kt_per + kk) * 4 + gq) * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)nw[j]) * rbf(bf2f((bf16_t)v[j]) * rstd));
+                    *reinterpret_cast<bf16x8*>(xs + u * 16) = v;
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
