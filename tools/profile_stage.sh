@@ -9,6 +9,7 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG -o stage -- python tools/sta
 grep ' ms per repetition' gpurun_out/$TAG/stage.log || tail -5 gpurun_out/$TAG/stage.log
 DB=$(ls gpurun_out/$TAG/*results.db 2>/dev/null | head -1)
 python tools/rocpd_stats.py "$DB" gpurun_out/${TAG}_kernel_stats.csv
+BY_GRID=1 python tools/rocpd_stats.py "$DB" gpurun_out/${TAG}_kernel_stats_by_grid.csv
 rm -rf gpurun_out/$TAG
 python - <<PY
 import csv

@@ -25,6 +25,25 @@ def main():
     reps = int(os.environ.get("REPS", "10"))
     dev = torch.device("cuda", 0)
     cfg = UniMedVLConfig()
+    if stage in ("vae", "vae_enc"):       # the full-size AutoEncoder alone: B images of HW x HW (decode) / (encode)
+        from bench import synth_vae
+        hw = int(os.environ.get("HW", "256"))
+        vae = synth_vae(cfg, dev)
+        g = torch.Generator(device=dev).manual_seed(1)
+        if stage == "vae":
+            lats = [torch.randn((hw // 16) ** 2, 4 * cfg.z_channels, device=dev, generator=g) for _ in range(B)]
+            fn = lambda: vae.decode_tokens_batch_to_uint8(lats, (hw, hw), 16, 2)   # noqa: E731
+        else:
+            img = torch.randn(B, 3, hw, hw, device=dev, generator=g).clamp(-1, 1)
+            fn = lambda: vae.encode(img)   # noqa: E731
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        print(f"{stage}: {(time.time() - t0) / reps * 1e3:.3f} ms per repetition ({reps} reps), B={B} {hw}x{hw}")
+        return
     cfg.llm_weight_dtype = os.environ.get("WEIGHTS", "bf16")
     if os.environ.get("ACT8", "0") != "0":
         cfg.llm_act_dtype = "fp8"
