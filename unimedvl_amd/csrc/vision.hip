@@ -2,6 +2,7 @@
 // NHWC implicit-GEMM convolutions on MFMA, GroupNorm(+swish), latent (un)patchify,
 // sampling and pixel conversion.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/unimedvl_hip.h"
 
 // ----------------------------------------------------------------------------- CFG + renorm + Euler
@@ -345,6 +346,198 @@ __global__ __launch_bounds__(WN * WM * 64) void conv_tiled_kernel(const bf16_t* 
     }
 }
 
+// ----------------------------------------------------------------------------- VAE: 3x3 convolution, input-stationary
+// conv_tiled_kernel gathers the im2col fragment of every filter tap from global memory: each input pixel goes through the
+// texture-address path NINE times, 16 bytes per lane from a different pixel row each (16 half cache lines per wave instruction).
+// At 128-512 channels that path, not the matrix pipe, sets the pace: 768 address cycles against 544 MFMA cycles per k-step on
+// a CU, 190-260 TFLOP/s on the decoder's 3x3 convolutions (profiles/r03_vae4_kernel_stats_by_grid.csv).
+// Here the INPUT stays put: a workgroup owns a 16 x 16 output tile and 128 output channels; for every 64-channel slice of the
+// input it brings the 18 x 18 pixel patch (halo included) into LDS ONCE - 40.5 KiB, pixel-major, 128 bytes per pixel with the
+// 16-byte channel octets XOR-swizzled by the pixel index - and all nine taps read their MFMA B fragments from that patch at
+// shifted pixel positions (16 consecutive pixels of a patch row per 16-lane row: conflict-free ds_read_b128).  Only the weights
+// stream per tap (16 KiB = 8 n-tiles x 2 k-tiles, straight copies of the packed image, 3-deep ring).  Per (slice, tap) step a
+// wave issues exactly three LDS-DMA pieces (two weight tiles + one piece of the NEXT slice's patch or a dummy), so the counted
+// vmcnt waits see a uniform queue; one raw barrier per step.  Same MFMA operands in the same k order (tap-major, channel-minor
+// inside a 64-channel slice... the k order is (slice, tap, channel) instead of (tap, channel): another fp32 summation order,
+// same bf16 rounding points (bias, residual) as conv_tiled_kernel.
+// MODE 1 = the nearest-2x upsample of Upsample.forward (autoencoder.py:116-118) fused in: the 16 x 16 OUTPUT tile reads a 10 x 10
+// patch of the half-resolution input (output pixel (oy, ox), tap (dy, dx) -> input ((oy + dy - 1) >> 1, (ox + dx - 1) >> 1); lanes
+// that share an input pixel read the same LDS address: a broadcast, not a conflict).
+#define CP_TW 16
+#define CP_TH 16
+#define CP_WBUF 16384                                // 8 n-tiles x 2 k-tiles
+template <int MODE> struct CpGeo {
+    static constexpr int PW = MODE == 1 ? CP_TW / 2 + 2 : CP_TW + 2;
+    static constexpr int PH = MODE == 1 ? CP_TH / 2 + 2 : CP_TH + 2;
+    static constexpr int PIX = PW * PH;                                      // 324 / 100 patch pixels
+    static constexpr int PATCH_BYTES = (PIX * 128 + 1023) / 1024 * 1024;     // 41 / 13 DMA pieces of 1 KiB
+    static constexpr int PIECES = PATCH_BYTES / 1024;
+    static constexpr int LDS = 2 * PATCH_BYTES + 3 * CP_WBUF + 1024;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                            bf16_t* __restrict__ out, int B, int H, int W, int Cin, int Cout, int KT,
+                                                            int NTT, int tiles_x, int tiles_y) {
+    // H, W: OUTPUT size (MODE 1: the input is H/2 x W/2)
+    constexpr int CP_PW = CpGeo<MODE>::PW, CP_PIX = CpGeo<MODE>::PIX, CP_PATCH_BYTES = CpGeo<MODE>::PATCH_BYTES, CP_PATCH_PIECES = CpGeo<MODE>::PIECES;
+    const int Hi = MODE == 1 ? H / 2 : H, Wi = MODE == 1 ? W / 2 : W;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;                               // 2 buffers
+    char* wbuf = smem + 2 * CP_PATCH_BYTES;           // 3 buffers
+    char* dummy = wbuf + 3 * CP_WBUF;                 // 1 KiB sink of the padding pieces
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;          // 2 (n) x 4 (m) waves of 64 channels x 64 pixels (4 tile rows)
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b = bid % B;
+    const int nblk = bid / B;
+    const int ox0 = tx * CP_TW, oy0 = ty * CP_TH;
+    const int nt_blk = nblk * 8;
+    const int nslices = Cin / 64;
+    const int nsteps = nslices * 9;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_v);
+    const bf16_t* xb = x + (int64_t)b * Hi * Wi * Cin;
+    const int iy0 = MODE == 1 ? oy0 / 2 - 1 : oy0 - 1, ix0 = MODE == 1 ? ox0 / 2 - 1 : ox0 - 1;     // input coordinates of patch pixel (0, 0)
+
+    // ---- LDS-DMA pieces of a step: W tiles f = wave*2 + {0,1} (n-tile f/2.. : tile index t = f >> 1?  8 n-tiles x 2 k-tiles = 16 pieces)
+    auto stage_w = [&](int step, int buf) {
+        const int slice = step / 9, tap = step - slice * 9;
+        const int kt0 = (tap * Cin + slice * 64) >> 5;            // k-tile of the packed image: k = tap*Cin + ci
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = wave * 2 + i;                           // piece = (n-tile f >> 1, k-tile f & 1)
+            const int nt = nt_blk + (f >> 1);
+            const bf16_t* p = nt < NTT ? wp + ((int64_t)nt * KT + kt0 + (f & 1)) * 512 + lane * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_v)(wbuf + buf * CP_WBUF + f * 1024), 16, 0, 0);
+        }
+    };
+    // piece q (0..40) of the patch of `slice`: 64 consecutive 16-byte slots s = q*64 + lane = pixel*8 + pos; the slot holds channel
+    // octet pos ^ (pixel & 7) of that pixel (the swizzle is applied on the SOURCE side: the LDS image of a DMA is lane-linear)
+    auto stage_patch_piece = [&](int slice, int q, int buf) {
+        const int sidx = q * 64 + lane;
+        const int pix = sidx >> 3, pos = sidx & 7;
+        const int py = pix / CP_PW, px = pix - py * CP_PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const int oct = pos ^ (pix & 7);
+        const bool ok = pix < CP_PIX && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+        const bf16_t* p = ok ? xb + ((int64_t)iy * Wi + ix) * Cin + slice * 64 + oct * 8 : zero;
+        __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_v)(patch + buf * CP_PATCH_BYTES + q * 1024), 16, 0, 0);
+    };
+    // the third piece of step (slice, tap): a piece of the NEXT slice's patch during taps 0..5 - into the buffer the PREVIOUS
+    // slice used, which every wave has left by then - else a dummy
+    auto stage_third = [&](int slice, int tap) {
+        const int q = tap * 8 + wave;                              // 6 taps x 8 waves = 48 >= 41 (13) pieces
+        if (tap < 6 && q < CP_PATCH_PIECES && slice + 1 < nslices) stage_patch_piece(slice + 1, q, (slice + 1) & 1);
+        else __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_v)dummy, 16, 0, 0);
+    };
+
+    // ---- prologue: patch of slice 0 (all 41 pieces, 5-6 per wave), then W(0), W(1) with a dummy behind each: the queue of a
+    //      wave then looks like the steady state (per step: two weight pieces for step + 2, then one third piece)
+    for (int q = wave; q < CP_PATCH_PIECES; q += 8) stage_patch_piece(0, q, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_w(0, 0);
+    __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_v)dummy, 16, 0, 0);
+    stage_w(1, 1);
+    __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_v)dummy, 16, 0, 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int step = 0; step < nsteps; ++step) {
+        // W(step) was issued two steps ago; behind it in the queue: that step's third piece, W(step + 1) and its third piece = 4
+        // pieces that may still be in flight (the patch of a slice is issued during taps 0..5 of the slice before: long landed)
+        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int slice = step / 9, tap = step - slice * 9;
+        if (step + 2 < nsteps) stage_w(step + 2, (step + 2) % 3);
+        else {      // (keep three pieces per step to the end)
+            __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_v)dummy, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_v)dummy, 16, 0, 0);
+        }
+        stage_third(slice, tap);
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const char* wb = wbuf + (step % 3) * CP_WBUF;
+        const char* pb = patch + (slice & 1) * CP_PATCH_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(wb + (((wn * 4 + t) * 2 + kk) * 1024) + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // patch pixel of output (tile row wm*4+j, column r) at this tap
+                const int pix = MODE == 1 ? ((wm * 4 + j + dy + 1) >> 1) * CP_PW + ((r + dx + 1) >> 1) : (wm * 4 + j + dy) * CP_PW + r + dx;
+                xf[j] = *reinterpret_cast<const bf16x8*>(pb + pix * 128 + (((kk * 4 + g) ^ (pix & 7)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = mfma16(wf[t], xf[j], acc[t][j]);
+        }
+    }
+    // ---- epilogue: + bias -> bf16 ; (+ residual -> bf16); lane (r, g) of tile (t, j) holds pixel column r, channels n0..n0+3
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n0 = (nt_blk + wn * 4 + t) * 16 + g * 4;
+        if (n0 >= Cout) continue;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(bias + n0);
+            b4[0] = __uint_as_float(pk.x << 16); b4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+            b4[2] = __uint_as_float(pk.y << 16); b4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = oy0 + wm * 4 + j, ox = ox0 + r;
+            if (oy >= H || ox >= W) continue;
+            const int64_t m = ((int64_t)b * H + oy) * W + ox;
+            const float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
+            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (residual) {
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(residual + m * Cout + n0);
+                r4[0] = __uint_as_float(pk.x << 16); r4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+                r4[2] = __uint_as_float(pk.y << 16); r4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+            }
+            float f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f[q] = rbf(bias ? v[q] + b4[q] : v[q] + 0.f);
+                if (residual) f[q] = rbf(f[q] + r4[q]);
+            }
+            u32x2 pk;
+            pk.x = pack2bf(f[0], f[1]);
+            pk.y = pack2bf(f[2], f[3]);
+            *reinterpret_cast<u32x2*>(out + m * Cout + n0) = pk;
+        }
+    }
+}
+
+template <int MODE>
+static int launch_conv_patch(const bf16_t* x, const bf16_t* wp, const bf16_t* bias, const bf16_t* residual, bf16_t* out, int B, int H, int W,
+                             int Cin, int Cout, int KT, int NTT, hipStream_t s) {
+    constexpr int CP_LDS = CpGeo<MODE>::LDS;
+    static bool attr_set[UMV_MAX_DEVICES] = {};
+    if (umv_first_on_device(attr_set)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CP_LDS);
+        UMV_CHECK(e == hipSuccess, UMV_ERR_LAUNCH, "conv3x3_patch: cannot reserve %d bytes of LDS", (int)CP_LDS);
+    }
+    const int tiles_x = (W + CP_TW - 1) / CP_TW, tiles_y = (H + CP_TH - 1) / CP_TH, nblocks = (Cout + 127) / 128;
+    hipLaunchKernelGGL(conv3x3_patch_kernel<MODE>, dim3(tiles_x * tiles_y * B * nblocks), dim3(512), CP_LDS, s, x, wp, bias, residual, out, B, H, W, Cin,
+                       Cout, KT, NTT, tiles_x, tiles_y);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF>
 static int launch_conv(const bf16_t* x, const bf16_t* wp, const bf16_t* bias, const bf16_t* residual, bf16_t* out, const ConvGeom& geo,
                        int KT, int NTT, hipStream_t s) {
@@ -369,7 +562,10 @@ extern "C" int umv_conv2d_nhwc_bf16(const uint16_t* x, const uint16_t* wp, const
                                     umv_stream_t stream) {
     UMV_CHECK(x && wp && out, UMV_ERR_ARG, "conv2d: null pointer");
     UMV_CHECK(Cin % 8 == 0, UMV_ERR_ARG, "conv2d: Cin (%d) must be a multiple of 8 (pad the input channels)", Cin);
-    UMV_CHECK((ksize == 3 || ksize == 1) && mode >= 0 && mode <= 2, UMV_ERR_ARG, "conv2d: ksize %d mode %d", ksize, mode);
+    const int force = mode & ~3;       // tests / A-B: | 16 = the input-stationary 3x3 kernel whatever the grid, | 32 = the gather kernel
+    mode &= 3;
+    UMV_CHECK((ksize == 3 || ksize == 1) && mode >= 0 && mode <= 2 && (force == 0 || force == 16 || force == 32), UMV_ERR_ARG,
+              "conv2d: ksize %d mode %d", ksize, mode | force);
     ConvGeom geo;
     geo.B = B; geo.Cin = Cin; geo.Hin = Hin; geo.Win = Win; geo.Cout = Cout; geo.ks = ksize; geo.mode = mode;
     if (mode == 0) { geo.Hout = Hin; geo.Wout = Win; }
@@ -380,6 +576,16 @@ extern "C" int umv_conv2d_nhwc_bf16(const uint16_t* x, const uint16_t* wp, const
     const int K = ksize * ksize * Cin;
     const int KT = (K + 31) / 32, NTT = (Cout + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
+    // 3x3, stride 1, input channels in whole 64-channel slices, 4-channel-aligned outputs, and enough 16 x 16 tiles to fill the
+    // chip: the input-stationary kernel
+    const bool patch_ok = ksize == 3 && (mode == 0 || mode == 1) && Cin % 64 == 0 && Cout % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(out)) & 7) == 0;
+    UMV_CHECK(force != 16 || patch_ok, UMV_ERR_UNSUPPORTED, "conv2d: the input-stationary kernel needs 3x3 / stride 1 / Cin %% 64 == 0 / Cout %% 4 == 0");
+    // (whatever the grid: even 16 workgroups of it beat the gather kernel on a 32 x 32 x 512 level, and a choice that depended
+    // on the batch would break "a batch == its images one by one, bit for bit")
+    if (patch_ok && force != 32)
+        return mode == 1 ? launch_conv_patch<1>(x, wp, bias, residual, out, B, geo.Hout, geo.Wout, Cin, Cout, KT, NTT, s)
+                         : launch_conv_patch<0>(x, wp, bias, residual, out, B, geo.Hout, geo.Wout, Cin, Cout, KT, NTT, s);
     if (Cout <= 16) return launch_conv<1, 4, 1, 4, 4, 2>(x, wp, bias, residual, out, geo, KT, NTT, s);     // conv_out: 16(n) x 256(m)
     const long wg128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
     if (wg128 >= 384) return launch_conv<2, 2, 4, 4, 2, 2>(x, wp, bias, residual, out, geo, KT, NTT, s);  // 128 x 128 x 64
