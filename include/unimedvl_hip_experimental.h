@@ -122,6 +122,13 @@ typedef struct {
 } umv_attn_decode_args;
 int umv_attn_decode_fused(const umv_attn_decode_args* a, umv_stream_t stream);
 
+/* Prefill attention on the 32x32x16 matrix instruction (csrc/attention_prefill32.hip): umv_attn_varlen's arguments, nsplit = 1 and
+ * hd = 128 only (flash_attn_varlen_func at qwen2_navit.py:605-614).  One wave owns 32 q columns, K Q^T / softmax / P V of three
+ * consecutive key blocks are software-pipelined, K / V^T blocks reach LDS as contiguous 1 KiB LDS-DMA pieces with a source-side
+ * swizzle.  Correct (tests/test_attn_prefill32_gpu.py) and as fast as the shipped attn_prefill_kernel, not faster
+ * (DESIGN.md section 5b has the counters and the ablation): kept here, not on the product path. */
+int umv_attn_prefill32(const umv_attn_args* a, umv_stream_t stream);
+
 /* Stream `bytes` at `ptr` through the cache hierarchy (no compute) so that they are resident in the
  * 256 MiB Infinity Cache for a later kernel; meant for a parallel stream / graph branch during the
  * latency-bound kernels of a decode step.  `sink` (4 bytes, may be NULL) only keeps the loads alive. */

@@ -152,6 +152,7 @@ _EXP_SIGS = {
     "umv_decode_engine_traced": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_void_p]),
     "umv_attn_decode_fused": (C.c_int, [C.POINTER(AttnDecodeArgs), C.c_void_p]),
+    "umv_attn_prefill32": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "umv_decode_layout_for": (C.c_int, [C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
     "umv_decode_image_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(DecodeLayout)]),
     "umv_repack_weight_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -20,7 +20,7 @@ LIB_EXPERIMENTAL = os.path.join(LIBDIR, "libunimedvl_hip_experimental.so")
 SOURCES = ["host_error.hip", "elementwise.hip", "gemm.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "vision.hip"]
 # ... and the experimental one (include/unimedvl_hip_experimental.h): measured, not adopted, kept with its tests; nothing on the
 # product path loads it
-SOURCES_EXPERIMENTAL = ["host_error.hip", "gemm_decode.hip", "attention_decode.hip", "decode_engine.hip", "prefetch.hip"]
+SOURCES_EXPERIMENTAL = ["host_error.hip", "gemm_decode.hip", "attention_decode.hip", "attention_prefill32.hip", "decode_engine.hip", "prefetch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 # per-file additions.  attention_prefill: MFMA destinations stay in VGPRs (the compiler's default parks the 64 O accumulators in

@@ -497,10 +497,12 @@ def attn_workspace(nseg, nq, hd, max_q, nsplit, device):
     return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
 
 
-def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None, k_packed=None):
+def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None, k_packed=None,
+              experimental32=False):
     """q: [T, nq*hd] or [T, nq, hd] rows, possibly a column slice of a wider buffer (row stride = q.stride(0)).
-    k_packed: [T, nkv*hd] column slice holding K row-aligned with q (cache-less self-attention): the K slab is not read."""
-    lib = _lib.load()
+    k_packed: [T, nkv*hd] column slice holding K row-aligned with q (cache-less self-attention): the K slab is not read.
+    experimental32: run umv_attn_prefill32 of the EXPERIMENTAL library instead (hd 128, nsplit 1; tests / tools only)."""
+    lib = _lib.load_experimental() if experimental32 else _lib.load()
     _req(q, BF16, "q")
     if q.stride(-1) != 1 or (q.dim() == 3 and q.stride(1) != hd):
         raise _lib.UmvError("attention: q rows must be contiguous [nq * hd] runs")
@@ -520,6 +522,9 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
         k_slab=k_ptr, vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
         causal=int(bool(causal)), max_q=max_q, max_kv=max_kv, nsplit=nsplit,
         workspace=None if workspace is None else workspace.data_ptr(), q_row_stride=q.stride(0), k_key_stride=k_key_stride, **strides)
+    if experimental32:
+        _lib.check_exp(lib.umv_attn_prefill32(C.byref(a), _stream()), "umv_attn_prefill32")
+        return out
     check(lib.umv_attn_varlen(C.byref(a), _stream()), "umv_attn_varlen")
     return out
 
