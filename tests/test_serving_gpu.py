@@ -58,12 +58,44 @@ def test_batcher_rejects_oversized_requests(model):
     from oracle.toy_tokenizer import ToyTokenizer
     from unimedvl_amd.serving import ContinuousBatcher
     tok = ToyTokenizer(NEW_TOKEN_IDS)
-    srv = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, lambda x: x, slots=2, max_context=16, max_new_tokens=4)
+    srv = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, lambda x: x, slots=2, max_context=16, max_new_tokens=4, growable=False)
     with pytest.raises(ValueError, match="reserve"):
         srv.submit(None, "5 6", max_new_tokens=9)
     srv.submit(None, " ".join(["7"] * 40))
     with pytest.raises(ValueError, match="max_context"):
         srv.run()
+
+
+@pytest.mark.parametrize("slots,check_every,use_graph", [(2, 3, True), (3, 4, True), (2, 5, False)])
+def test_batcher_grows_its_cache_for_long_requests(model, slots, check_every, use_graph):
+    """growable=True (the default; the reference's NaiveCache grows without bound, qwen2_navit.py:585-600): the slots are
+    reserved for the minimum (256 tokens per slot); a 280-token request in the middle of the queue and a 600-token one at its
+    end enlarge the slabs between decode rounds (256 -> 512 -> 1024), the decode step is re-captured and the slots that were
+    mid-answer continue.  Answers must be exactly those of one-request-at-a-time decoding, and the cache must have grown."""
+    from oracle.toy_tokenizer import ToyTokenizer
+    from unimedvl_amd.serving import ContinuousBatcher
+    tok = ToyTokenizer(NEW_TOKEN_IDS)
+    reqs = _requests(6)
+    g = torch.Generator().manual_seed(5)
+    reqs.append(([torch.randn(3, 56, 70, generator=g).clamp(-1, 1), torch.randn(3, 70, 70, generator=g).clamp(-1, 1)],
+                 " ".join(str(int(v)) for v in torch.randint(5, 290, (600,), generator=g))))      # the one that forces a second doubling
+    reqs[2] = (reqs[2][0], " ".join(str(int(v)) for v in torch.randint(5, 290, (280,), generator=g)))
+    budgets = [6, 3, 6, 5, 12, 2, 7]
+    ident = lambda x: x   # noqa: E731
+    want = [model.chat(tok, NEW_TOKEN_IDS, ident, images, prompt, max_length=nb + 1) for (images, prompt), nb in zip(reqs, budgets)]
+    srv = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, ident, slots=slots, max_context=16, max_new_tokens=8, check_every=check_every,
+                            use_graph=use_graph)
+    cap0 = srv.cache.cap
+    rids = [srv.submit(images, prompt, max_new_tokens=nb) for (images, prompt), nb in zip(reqs, budgets)]
+    got = srv.run()
+    for rid, w in zip(rids, want):
+        assert got[rid] == w, (rid, got[rid], w)
+    assert cap0 == 256 and srv.stats["cache_grows"] >= 2 and srv.cache.cap >= 1024
+    # a limit on the context is still available
+    lim = ContinuousBatcher(model, tok, NEW_TOKEN_IDS, ident, slots=2, max_context=16, max_new_tokens=4, context_limit=64)
+    lim.submit(None, " ".join(["7"] * 100))
+    with pytest.raises(ValueError, match="context_limit"):
+        lim.run()
 
 
 @pytest.mark.parametrize("slots,check_every", [(4, 3), (8, 4)])
@@ -120,6 +152,7 @@ def test_image_prefill_graph_equals_eager(model):
 
     eager, kvl, rope = run(NaiveCache(cfg.layers), imgs[:2])              # not reserved -> eager kernels
     assert not model._vit_graphs or True
+    model._vit_graphs.clear()          # the graph store is bounded (oldest entry dropped): count from empty
     n_before = len(model._vit_graphs)
     pooled = NaiveCache(cfg.layers)
     pooled.reserve(1, 512, cfg.kv_heads, cfg.head_dim, model.device)

@@ -5,9 +5,14 @@ The reference decodes one request at a time and stops a whole batch when SAMPLE 
 graph (decode.DecodeSession); every `check_every` steps the host looks at the generated ids, retires the slots that
 produced <|im_end|> (or hit their token budget) and prefills the next queued request straight into the freed slot:
 
-  * the KV cache is one slab per layer with a fixed per-slot capacity (kvcache.NaiveCache.reserve), so a new request is
-    a prefill on a ONE-SEGMENT VIEW of that slab (NaiveCache.view_segments) - no copy, no re-allocation, the other slots'
-    keys are untouched;
+  * the KV cache is one slab per layer with a per-slot capacity reserved up front (kvcache.NaiveCache.reserve), so a new
+    request is a prefill on a ONE-SEGMENT VIEW of that slab (NaiveCache.view_segments) - no copy, no re-allocation, the other
+    slots' keys are untouched;
+  * a request whose context does not fit that reservation GROWS the slabs (growable=True, the default: the reference's
+    NaiveCache grows without bound, qwen2_navit.py:585-600): between two decode rounds the cache doubles
+    (NaiveCache.ensure copies the committed keys), the decode session is re-captured on the new slabs and every active
+    slot continues from its next token - answers are unchanged (tests/test_serving_gpu.py).  growable=False keeps the
+    old contract: such a request is refused (ValueError) and nothing is re-allocated;
   * the graph reads each slot's next token / cache length / rope position from device memory
     (DecodeSession.set_slot), so re-pointing a slot needs no re-capture;
   * samples are independent rows of every kernel: a request's tokens are the same whichever slot and neighbours it gets
@@ -37,12 +42,16 @@ class _Request:
 class ContinuousBatcher:
     def __init__(self, model, tokenizer, new_token_ids, image_transform, slots: int = 8, max_context: int = 2048,
                  max_new_tokens: int = 256, check_every: int = 16, do_sample: bool = False, temperature: float = 1.0,
-                 use_graph: bool = True):
+                 use_graph: bool = True, growable: bool = True, context_limit: Optional[int] = None):
+        """max_context: the context (prompt + images) the slots are RESERVED for; with growable=True longer requests enlarge
+        the cache (up to context_limit tokens of context when given), with growable=False they are refused."""
         self.model, self.tokenizer, self.new_token_ids, self.image_transform = model, tokenizer, new_token_ids, image_transform
         self.device = model.device
         self.slots, self.check_every = int(slots), int(check_every)
         self.max_context, self.default_new = int(max_context), int(max_new_tokens)
         self.do_sample, self.temperature, self.use_graph = do_sample, temperature, use_graph
+        self.growable, self.context_limit = bool(growable), context_limit
+        self._grew = False
         cfg = model.cfg
         self.cache = NaiveCache(cfg.layers)
         self.cache.reserve(self.slots, self.max_context + self.default_new + self.check_every + 8, cfg.kv_heads, cfg.head_dim,
@@ -50,14 +59,14 @@ class ContinuousBatcher:
         self.queue: Deque[_Request] = deque()
         self.results: Dict[int, str] = {}
         self._next_id = 0
-        self.stats = {"decode_steps": 0, "prefills": 0, "tokens": 0}
+        self.stats = {"decode_steps": 0, "prefills": 0, "tokens": 0, "cache_grows": 0}
 
     # ------------------------------------------------------------------ API
     def submit(self, images, prompt: str, max_new_tokens: Optional[int] = None) -> int:
         """images: one image / a list of images (PIL or [3,H,W] tensors, as the transform accepts) or None."""
         imgs = [] if images is None else (list(images) if isinstance(images, (list, tuple)) else [images])
         budget = self.default_new if max_new_tokens is None else int(max_new_tokens)
-        if budget > self.default_new:
+        if budget > self.default_new and not self.growable:
             raise ValueError(f"max_new_tokens {budget} exceeds the batcher's reserve of {self.default_new}")
         rid = self._next_id
         self._next_id += 1
@@ -80,13 +89,18 @@ class ContinuousBatcher:
                 first.append(b)
         for b, st in zip(first, self._prefill_many(first, [active[b] for b in first])):
             state[b] = st
-        start = torch.tensor([s[0] for s in state], dtype=torch.int64)
-        pos = torch.tensor([s[2] for s in state], dtype=torch.int64)
         seed = m._sampling_seed() if self.do_sample else 0
-        lens_now = list(cache.lens)
-        sess = DecodeSession(m.language_model, cache, start, pos, self.check_every, use_graph=self.use_graph,
-                             do_sample=self.do_sample, temperature=self.temperature, seed=seed)
-        cache.lens = lens_now                           # the session only reads them; this loop owns the bookkeeping
+
+        def new_session():        # (re-)capture the decode step on the cache's current slabs; every slot continues from `state`
+            start = torch.tensor([s[0] for s in state], dtype=torch.int64)
+            pos = torch.tensor([s[2] for s in state], dtype=torch.int64)
+            lens_now = list(cache.lens)
+            sn = DecodeSession(m.language_model, cache, start, pos, self.check_every, use_graph=self.use_graph,
+                               do_sample=self.do_sample, temperature=self.temperature, seed=seed)
+            cache.lens = lens_now                       # the session only reads them; this loop owns the bookkeeping
+            self._grew = False
+            return sn
+        sess = new_session()
         while any(r is not None for r in active) or self._other_work():
             if not any(r is not None for r in active):  # only the other kind of work is left (MixedBatcher: flow passes)
                 self._between_rounds()
@@ -102,6 +116,7 @@ class ContinuousBatcher:
                 req = active[b]
                 if req is None:
                     sess.set_slot(b, bos, 0, 0)         # idle slot: keep it parked at the start of its segment
+                    state[b] = (bos, 0, 0)
                     continue
                 col = ids[:, b].tolist()
                 done = False
@@ -114,6 +129,7 @@ class ContinuousBatcher:
                     done = True
                 if not done:
                     cache.lens[b] += k                  # the graph advanced this slot's device counters by k as well
+                    state[b] = (col[-1], cache.lens[b], state[b][2] + k)
                     continue
                 self._finish(req)
                 active[b] = None
@@ -123,10 +139,14 @@ class ContinuousBatcher:
                     freed.append(b)
                 else:
                     sess.set_slot(b, bos, 0, 0)
+                    state[b] = (bos, 0, 0)
             # every slot that was freed this round is refilled by ONE batched prefill (images of the new requests share the
             # ViT and LLM forward; the other slots take part with zero query tokens)
             for b, (tok, kvl, rope) in zip(freed, self._prefill_many(freed, [active[b] for b in freed])):
                 sess.set_slot(b, tok, kvl, rope)
+                state[b] = (tok, kvl, rope)
+            if self._grew:                              # an admitted request enlarged the cache: new slabs, new captured step
+                sess = new_session()
         return dict(self.results)
 
     # ------------------------------------------------------------------ hooks (MixedBatcher)
@@ -140,16 +160,27 @@ class ContinuousBatcher:
     def _prefill(self, b: int, req: _Request):
         """Image(s) then the prompt into slot b (Bagel.chat's order, bagel.py:1321-1392); returns the slot's decode state."""
         m = self.model
+        self.cache.lens[b] = 0
         view = self.cache.view_segments(b, b + 1)
         view.lens = [0]
         cap = view.cap
         kvl, rope = [0], [0]
+
+        def room(n_ctx):          # growing re-allocates the pooled cache: commit what the view holds, take the view again
+            nonlocal view, cap
+            self.cache.lens[b] = view.lens[0]
+            new_cap = self._check_room(n_ctx, req, cap)
+            if new_cap != cap:
+                keep = view.lens[0]
+                view = self.cache.view_segments(b, b + 1)
+                view.lens = [keep]
+                cap = view.cap
         for image in req.images:
             gi, kvl, rope = m.prepare_vit_images(kvl, rope, [image], self.image_transform, self.new_token_ids)
-            self._check_room(kvl[0], req, cap)
+            room(kvl[0])
             view = m.forward_cache_update_vit(view, **gi)
         gi, kvl, rope = m.prepare_prompts(kvl, rope, [req.prompt], self.tokenizer, self.new_token_ids)
-        self._check_room(kvl[0], req, cap)
+        room(kvl[0])
         view = m.forward_cache_update_text(view, **gi)
         if view.cap != cap:
             raise RuntimeError("slot view was re-allocated: the request does not fit the reserved capacity")
@@ -182,13 +213,13 @@ class ContinuousBatcher:
         for j in range(len(reqs[0].images)):
             gi, kvl, rope = m.prepare_vit_images(kvl, rope, [r.images[j] for r in reqs], self.image_transform, self.new_token_ids)
             for n, r in zip(kvl, reqs):
-                self._check_room(n, r, cap)
+                cap = self._check_room(n, r, cap)
             gi["packed_seqlens"] = spread(gi["packed_seqlens"])
             gi["key_values_lens"] = gi["packed_key_value_indexes"] = gi["packed_indexes"] = None   # written for a k-sample cache
             m.forward_cache_update_vit(cache, **gi)
         gi, kvl, rope = m.prepare_prompts(kvl, rope, [r.prompt for r in reqs], self.tokenizer, self.new_token_ids)
         for n, r in zip(kvl, reqs):
-            self._check_room(n, r, cap)
+            cap = self._check_room(n, r, cap)
         gi["text_token_lens"] = spread(gi["text_token_lens"])
         gi["key_values_lens"] = gi["packed_key_value_indexes"] = gi["packed_text_indexes"] = None
         m.forward_cache_update_text(cache, **gi)
@@ -200,9 +231,27 @@ class ContinuousBatcher:
         self.stats["batched_prefills"] = self.stats.get("batched_prefills", 0) + 1
         return [(self.new_token_ids["bos_token_id"], n, r) for n, r in zip(kvl, rope)]
 
-    def _check_room(self, ctx_tokens: int, req: _Request, cap: int):
-        if ctx_tokens > self.max_context or ctx_tokens + req.max_new_tokens + self.check_every + 1 > cap:
+    def _check_room(self, ctx_tokens: int, req: _Request, cap: int) -> int:
+        """Room for `ctx_tokens` of context + the request's new tokens in a slot?  Returns the capacity to go on with: the
+        same, or - growable - the enlarged one (the pooled cache is re-allocated HERE, before the forward that would write
+        past the old slabs; run() re-captures the decode session afterwards)."""
+        need = ctx_tokens + req.max_new_tokens + self.check_every + 1
+        if ctx_tokens <= self.max_context and need <= cap:
+            return cap
+        if not self.growable:
             raise ValueError(f"request {req.rid}: context of {ctx_tokens} tokens exceeds max_context={self.max_context}")
+        if self.context_limit is not None and ctx_tokens > self.context_limit:
+            raise ValueError(f"request {req.rid}: context of {ctx_tokens} tokens exceeds context_limit={self.context_limit}")
+        if need > cap:
+            cfg = self.model.cfg
+            lens = list(self.cache.lens)
+            self.cache.reserved = False
+            self.cache.ensure(self.slots, need, cfg.kv_heads, cfg.head_dim, self.model.device)     # >= 2 x the old capacity
+            self.cache.reserved = True
+            self.cache.lens = lens
+            self._grew = True
+            self.stats["cache_grows"] += 1
+        return self.cache.cap
 
     def _finish(self, req: _Request):
         bos = self.new_token_ids["bos_token_id"]
