@@ -301,6 +301,16 @@ int umv_unpatchify_latent(const float* tokens, uint16_t* out, int h, int w, int 
 /* decoder output NHWC bf16 (first 3 of Cs channels) -> uint8 HWC: (x*0.5+0.5).clamp(0,1)*255,
  * truncating cast (inferencer.py:253-254) */
 int umv_pixels_to_u8(const uint16_t* x, uint8_t* out, int64_t npix, int Cs, umv_stream_t stream);
+/* AttnBlock.attention (autoencoder.py:50-62: one head of C channels over H*W positions) as two umv_gemm_bf16 calls with fp32
+ * outputs, S = Q K^T and O = P V, and these two row kernels between / after them (unimedvl_amd/vae.py::attnblock):
+ *   umv_softmax_rows_f32:  P[r][c] = bf16(exp((S[r][c] - max_c S[r][c]) * scale)), l[r] = sum_c of the unrounded weights
+ *                          (n even, <= 16384 columns; S [rows, ld_s] fp32, P [rows, ld_p] bf16)
+ *   umv_rowscale_f32_bf16: out[r][c] = bf16(O[r][c] / l[r])
+ * - the arithmetic of flash attention (fp32 scores and sums, bf16 weights, one division) with the row's true maximum. */
+int umv_softmax_rows_f32(const float* S, int64_t ld_s, uint16_t* P, int64_t ld_p, float* l, int rows, int n, float scale,
+                         umv_stream_t stream);
+int umv_rowscale_f32_bf16(const float* O, int64_t ld_in, const float* l, uint16_t* out, int64_t ld_out, int rows, int C,
+                          umv_stream_t stream);
 /* encoder tail for sample b: moments NHWC [B,Hm,Wm,2z] + noise NCHW bf16 [B,z,Hm,Wm] ->
  * scale*(mean + exp(0.5*logvar)*noise - shift) (autoencoder.py:266-272,300-303), 2x2-patchified
  * tokens [h*w, p*p*z] of the top-left window (bagel.py:771-775) */

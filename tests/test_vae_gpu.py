@@ -195,3 +195,72 @@ def test_edit_prefill_vs_reference(vae, tiny_weights):
     for got, ref, name in ((k0, g["k0"].float(), "k0"), (vL, g["vL"].float(), "vL")):
         err = (got - ref).abs().max().item()
         assert err <= 3e-2 * ref.abs().max().item(), f"{name}: max err {err} vs scale {ref.abs().max().item()}"
+
+
+def test_attnblock_gemm_form_vs_streaming_kernel_and_fp32_model(tiny_weights):
+    """AttnBlock.attention (autoencoder.py:50-62) at FULL width (one head of 512 channels, 28 x 28 = 784 and 56 x 56 = 3136
+    positions, two samples): the two-GEMM form (umv_softmax_rows_f32 / umv_rowscale_f32_bf16 between the GEMMs) against an fp32
+    model of the flash arithmetic and against the streaming attention kernel it replaces; per sample, so batched == single."""
+    import math
+    from unimedvl_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    C_ = 512
+    for n in (784, 3136):
+        B = 2
+        qkv = (torch.randn(B * n, 3 * C_, generator=g) * 1.5).to(BF16).cuda()
+        # fp32 model: scores from the bf16 operands, softmax in fp32, weights rounded to bf16 against the row maximum
+        ref = torch.empty(B * n, C_, device="cuda")
+        for b in range(B):
+            q, k, v = (qkv[b * n:(b + 1) * n, i * C_:(i + 1) * C_].float() for i in range(3))
+            s = q @ k.t() / math.sqrt(C_)
+            p = torch.exp(s - s.max(-1, keepdim=True).values)
+            ref[b * n:(b + 1) * n] = (p.to(BF16).float() @ v) / p.sum(-1, keepdim=True)
+        # the two-GEMM form, exactly as vae.py::attnblock runs it
+        o = torch.empty((B * n, C_), dtype=BF16, device="cuda")
+        S = torch.empty((n, n), dtype=torch.float32, device="cuda")
+        P = torch.empty((n, n), dtype=BF16, device="cuda")
+        l = torch.empty((n,), dtype=torch.float32, device="cuda")
+        Of = torch.empty((n, C_), dtype=torch.float32, device="cuda")
+        for b in range(B):
+            rows = slice(b * n, (b + 1) * n)
+            ops.gemm(qkv[rows, :C_], ops.PackedLinear.from_weight(qkv[rows, C_:2 * C_].contiguous()), out=S, out_f32=True)
+            _lib.check(lib.umv_softmax_rows_f32(S.data_ptr(), n, P.data_ptr(), n, l.data_ptr(), n, n, C_ ** -0.5, ops._stream()), "softmax")
+            ops.gemm(P, ops.PackedLinear.from_weight(qkv[rows, 2 * C_:].t().contiguous()), out=Of, out_f32=True)
+            _lib.check(lib.umv_rowscale_f32_bf16(Of.data_ptr(), C_, l.data_ptr(), o[rows].data_ptr(), C_, n, C_, ops._stream()), "rowscale")
+        assert torch.isfinite(o.float()).all()
+        d = (o.float() - ref).abs()
+        assert d.max().item() <= 2e-3 + 2 ** -7 * ref.abs().max().item(), (n, d.max().item())
+        assert (o == ref.to(BF16)).float().mean().item() > 0.85, "most elements must agree with the fp32 model to the last bf16 bit"
+        # the streaming kernel (online softmax in 32-key blocks) agrees to a few bf16 ulps
+        slab = ops.KVSlab(B, 1, (n + 31) // 32 * 32, C_, "cuda")
+        seg = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(n)
+        slot = torch.arange(n, dtype=torch.int32, device="cuda").repeat(B)
+        qq = torch.empty((B * n, 1, C_), dtype=BF16, device="cuda")
+        ops.qkv_post(qkv, qq, slab, seg, slot, None, 1, 1, C_)
+        o2 = torch.empty((B * n, 1, C_), dtype=BF16, device="cuda")
+        ops.attention(qq, o2, slab, torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device="cuda"),
+                      torch.full((B,), n, dtype=torch.int32, device="cuda"), 1, 1, C_, False, n, n)
+        assert (o.float() - o2.view(B * n, C_).float()).abs().max().item() <= 2e-3 + 2 ** -6 * ref.abs().max().item()
+
+
+def test_softmax_rows_argument_errors():
+    from unimedvl_amd import _lib, ops
+    lib = _lib.load()
+    S = torch.zeros((4, 10), dtype=torch.float32, device="cuda")
+    P = torch.zeros((4, 10), dtype=BF16, device="cuda")
+    l = torch.zeros(4, dtype=torch.float32, device="cuda")
+    assert lib.umv_softmax_rows_f32(S.data_ptr(), 10, P.data_ptr(), 10, l.data_ptr(), 4, 9, 1.0, ops._stream()) != 0      # odd n
+    assert lib.umv_softmax_rows_f32(S.data_ptr(), 10, P.data_ptr(), 10, l.data_ptr(), 4, 20000, 1.0, ops._stream()) != 0  # too wide
+    assert lib.umv_softmax_rows_f32(S.data_ptr(), 10, P.data_ptr(), 10, l.data_ptr(), 4, 10, 1.0, ops._stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(l.cpu(), torch.full((4,), 10.0)) and (P.float() == 1).all()
+    # the wide variant (8192 < n <= 16384: a 1024 x 1024 image's latent) against torch
+    g = torch.Generator().manual_seed(3)
+    S2 = (torch.randn(8, 16384, generator=g) * 3).cuda()
+    P2 = torch.zeros((8, 16384), dtype=BF16, device="cuda")
+    l2 = torch.zeros(8, dtype=torch.float32, device="cuda")
+    assert lib.umv_softmax_rows_f32(S2.data_ptr(), 16384, P2.data_ptr(), 16384, l2.data_ptr(), 8, 16384, 0.5, ops._stream()) == 0
+    torch.cuda.synchronize()
+    ref = torch.exp((S2 - S2.max(-1, keepdim=True).values) * 0.5)
+    assert torch.allclose(l2, ref.sum(-1), rtol=1e-5) and (P2.float() - ref).abs().max().item() <= 2 ** -8

@@ -856,3 +856,82 @@ extern "C" int umv_latent_sample_patchify(const uint16_t* moments, const uint16_
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
+
+// ----------------------------------------------------------------------------- single-head attention of the VAE mid block as two GEMMs
+// AttnBlock.attention (autoencoder.py:50-62) is ONE head of C = 512 channels over H*W positions: as S = Q K^T and O = P V those are
+// ordinary GEMMs at the tiled kernel's rate (3136 x 3136 x 512 at 448 x 448), where the streaming attention kernel at hd 512 keeps
+// 128 accumulator registers per lane and runs at 27 TFLOP/s (750 us of a 4.1 ms encode).  Between the GEMMs:
+//   umv_softmax_rows_f32:   P[r][c] = bf16(exp((S[r][c] - max_c S[r][c]) * scale)), l[r] = sum_c of the unrounded weights
+//   umv_rowscale_f32_bf16:  out[r][c] = bf16(O[r][c] / l[r])
+// i.e. the flash-attention arithmetic (fp32 scores and sums, bf16 weights, one division at the end) with the row's true maximum.
+template <int MAXI>             // 2 columns per thread and pass: n <= 2 * 256 * MAXI (16: 8192, 32: 16384 = a 1024 x 1024 image's latent)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* S, int64_t lds_, bf16_t* P, int64_t ldp, float* l, int n,
+                                                           float scale_log2e) {
+    __shared__ float red[8];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = S + (int64_t)r * lds_;
+    float2 v[MAXI];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = 2 * (tid + 256 * i);
+        v[i] = c < n ? *reinterpret_cast<const float2*>(s + c) : make_float2(-INFINITY, -INFINITY);
+        mx = fmaxf(mx, fmaxf(v[i].x, v[i].y));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mref = (mx == -INFINITY) ? 0.f : mx;
+    float sum = 0.f;
+    bf16_t* p = P + (int64_t)r * ldp;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = 2 * (tid + 256 * i);
+        if (c < n) {
+            const float p0 = umv_exp2((v[i].x - mref) * scale_log2e), p1 = umv_exp2((v[i].y - mref) * scale_log2e);
+            sum += p0;
+            sum += p1;
+            *reinterpret_cast<uint32_t*>(p + c) = pack2bf(p0, p1);
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    if (tid == 0) l[r] = (red[4] + red[5]) + (red[6] + red[7]);
+}
+extern "C" int umv_softmax_rows_f32(const float* S, int64_t ld_s, uint16_t* P, int64_t ld_p, float* l, int rows, int n, float scale,
+                                    umv_stream_t stream) {
+    UMV_CHECK(S && P && l, UMV_ERR_ARG, "softmax_rows: null pointer");
+    UMV_CHECK(n > 0 && n <= 16384 && (n % 2) == 0 && (ld_s % 2) == 0 && (ld_p % 2) == 0 && ld_s >= n && ld_p >= n, UMV_ERR_UNSUPPORTED,
+              "softmax_rows: n (%d) must be even and <= 16384, row strides even and >= n", n);
+    if (rows <= 0) return UMV_OK;
+    if (n <= 8192)
+        hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, ld_s, P, ld_p, l, n, scale * 1.4426950408889634f);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<32>, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, ld_s, P, ld_p, l, n, scale * 1.4426950408889634f);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* O, int64_t ldo_in, const float* l, bf16_t* out, int64_t ldo, int rows, int C) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = C / 2;
+    const int64_t r = gid / cpr;
+    if (r >= rows) return;
+    const int c = (int)(gid - r * cpr) * 2;
+    const float lv = l[r];
+    const float inv = lv > 0.f ? 1.0f / lv : 0.f;
+    const float2 v = *reinterpret_cast<const float2*>(O + r * ldo_in + c);
+    *reinterpret_cast<uint32_t*>(out + r * ldo + c) = pack2bf(v.x * inv, v.y * inv);
+}
+extern "C" int umv_rowscale_f32_bf16(const float* O, int64_t ld_in, const float* l, uint16_t* out, int64_t ld_out, int rows, int C,
+                                     umv_stream_t stream) {
+    UMV_CHECK(O && l && out, UMV_ERR_ARG, "rowscale: null pointer");
+    UMV_CHECK(C > 0 && (C % 2) == 0 && (ld_in % 2) == 0 && (ld_out % 2) == 0, UMV_ERR_ARG, "rowscale: C and the row strides must be even");
+    if (rows <= 0) return UMV_OK;
+    const int64_t total = (int64_t)rows * (C / 2);
+    hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, O, ld_in, l, out, ld_out, rows, C);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}

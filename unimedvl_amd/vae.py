@@ -11,6 +11,7 @@ mid-block attention reuses the varlen attention kernel (single head of C channel
 cannot match it, so the noise is a host-side input here.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -51,6 +52,7 @@ class AutoEncoder:
         lib = _lib.load()
         self._lib = lib
         self._ws = None
+        self.attn_as_gemm = os.environ.get("UMV_VAE_ATTN_GEMM", "1") not in ("0", "")   # A/B only: 0 = the streaming attention kernel
 
     # ------------------------------------------------------------------ lazy parameter access
     def _conv_w(self, name):
@@ -126,6 +128,31 @@ class AutoEncoder:
         T = B * H * W
         qkv = ops.gemm(h.view(T, Cc), lin)
         n = H * W
+        if n % 8 == 0 and 256 <= n <= 16384 and self.attn_as_gemm:
+            # one head of Cc channels: S = Q K^T and O = P V are plain GEMMs at the tiled kernel's rate (per sample: K and V^T of
+            # a sample are that GEMM's weight), fp32 scores, softmax rows and the final division in two small kernels:
+            # 750 -> ~100 us at 448 x 448 against the streaming attention kernel at head dim 512.  Query rows go in chunks
+            # that keep the fp32 score block under 256 MB (one chunk up to 8192 positions, 4 at a 1024 x 1024 image's 16384).
+            lib = _lib.load()
+            rc = n if n * n <= (64 << 20) else max(256, ((64 << 20) // n) // 256 * 256)
+            o = torch.empty((T, Cc), dtype=BF16, device=x.device)
+            S = torch.empty((rc, n), dtype=torch.float32, device=x.device)
+            P = torch.empty((rc, n), dtype=BF16, device=x.device)
+            l = torch.empty((rc,), dtype=torch.float32, device=x.device)
+            Of = torch.empty((rc, Cc), dtype=torch.float32, device=x.device)
+            for b in range(B):
+                lin_k = ops.PackedLinear.from_weight(qkv[b * n:(b + 1) * n, Cc:2 * Cc].contiguous())        # [N = n keys, K = Cc]
+                lin_v = ops.PackedLinear.from_weight(qkv[b * n:(b + 1) * n, 2 * Cc:].t().contiguous())      # V^T: [N = Cc, K = n keys]
+                for r0 in range(0, n, rc):
+                    m = min(rc, n - r0)
+                    rows = slice(b * n + r0, b * n + r0 + m)
+                    ops.gemm(qkv[rows, :Cc], lin_k, out=S, out_f32=True)
+                    _lib.check(lib.umv_softmax_rows_f32(S.data_ptr(), n, P.data_ptr(), n, l.data_ptr(), m, n, float(Cc) ** -0.5, _stream()),
+                               "umv_softmax_rows_f32")
+                    ops.gemm(P[:m], lin_v, out=Of, out_f32=True)
+                    _lib.check(lib.umv_rowscale_f32_bf16(Of.data_ptr(), Cc, l.data_ptr(), o[rows].data_ptr(), Cc, m, Cc, _stream()),
+                               "umv_rowscale_f32_bf16")
+            return self.conv(o.view(B, H, W, Cc), p + "proj_out", residual=x)
         slab = ops.KVSlab(B, 1, (n + 31) // 32 * 32, Cc, x.device)
         seg = torch.arange(B, dtype=torch.int32, device=x.device).repeat_interleave(n)
         slot = torch.arange(n, dtype=torch.int32, device=x.device).repeat(B)
