@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
     stage(0, 0);
     for (int sidx = 0; sidx < nstages; ++sidx) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my part of stage sidx has landed
-        __builtin_amdgcn_s_barrier();                            // ... everyone's; and everyone is done with stage sidx-1
+        UMV_BARRIER();                            // ... everyone's; and everyone is done with stage sidx-1
         if (sidx + 1 < nstages) stage(sidx + 1, (sidx + 1) & 1); // overlaps the math below
         const char* sb = smem + (sidx & 1) * STAGE;
 #pragma unroll

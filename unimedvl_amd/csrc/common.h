@@ -12,6 +12,12 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define UMV_WAVE 64
 
+// Workgroup barrier that the COMPILER also honours as a memory barrier.  __builtin_amdgcn_s_barrier() orders side effects but not
+// plain loads: an LDS read of data that the barrier publishes (a tile other waves staged by LDS-DMA behind their own counted
+// s_waitcnt) may be hoisted above it - seen in attention_prefill32.hip, where the first K / V^T fragment reads of an iteration
+// landed in front of the barrier and read stale fragments now and then.  The asm form with a "memory" clobber cannot move.
+#define UMV_BARRIER() asm volatile("s_barrier" ::: "memory")
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even fp32 -> bf16 on the gfx950 converter (v_cvt_pk_bf16_f32: one instruction for two values instead

@@ -870,7 +870,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
         };
         wait_tiles(NBUF - 2);
-        __builtin_amdgcn_s_barrier();
+        UMV_BARRIER();
         static_for<0, TN>([&](auto T) {
             constexpr int t = decltype(T)::value;
             lds_read_frag<t * 1024>(wfA[t], lds0 + woff);
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         static_assert(SCHED != 1 || TPW <= NMMA, "at most one DMA piece per MFMA");
         auto body = [&](int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
             wait_tiles(NBUF - 3);                                        // tile step+1 landed (mine); tile step+2's pieces may fly
-            __builtin_amdgcn_s_barrier();                                // ... everyone's; and tile step-1's buffer is free
+            UMV_BARRIER();                                // ... everyone's; and tile step-1's buffer is free
             const int st = step + NBUF - 1;                              // the tile staged during this step
             if (st >= nsteps) {
 #pragma unroll
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        UMV_BARRIER();
         if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
         const char* wb = smem + cur * BUF;
         const char* xb = wb + WTILES * 1024;
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     // bf16 outputs leave through LDS as whole rows (gemm_epilogue.h); fp32 outputs (split-K partials, OUT_F32) directly
     constexpr bool LDS_EPI = BN * BM * 2 <= NBUF * BUF;
     if (LDS_EPI && !(e.flags & UMV_EPI_OUT_F32) && lds_epilogue_enabled) {
-        __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the staging buffers are free
+        UMV_BARRIER();      // every wave has read its last fragments: the staging buffers are free
         epi_wave_tile_lds<TN, TM>(e, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, a.M, a.row_idx, nt_base, NTT,
                                   bias_lds + wn * TN * 16);
         return;

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
     for (int kt = 0; kt < KT; ++kt) {
         if (DMA_IN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * TPW) : "memory");   // step kt landed (mine); newer ones fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        UMV_BARRIER();
         const int kst = kt + NBUF - 1, bst = kst % NBUF;
         if constexpr (!DMA_IN) {
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
     // epilogue: exact power-of-two scales, then the shared bf16 epilogue (bias / activation / SwiGLU / residual)
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
     if constexpr (BN * BM * 2 <= NBUF * BUF) {   // whole rows through LDS (gemm_epilogue.h): same values, 16-byte stores
-        __builtin_amdgcn_s_barrier();             // every wave has read its last fragments: the staging buffers are free
+        UMV_BARRIER();             // every wave has read its last fragments: the staging buffers are free
         epi_wave_tile_lds<TN, TM>(e, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, a.M, a.row_idx, nt_base, NTT, nullptr,
                                   a.w_scale, a.x_scale);
         return;

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WN * WM * 64) void conv_tiled_kernel(const bf16_t* 
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        UMV_BARRIER();
         if (step + NBUF - 1 < nsteps) stage(step + NBUF - 1, (step + NBUF - 1) % NBUF);
         const char* wb = smem + cur * BUF;
         const char* xb = wb + WTILES * 1024;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const bf16_t* __rest
         // pieces that may still be in flight (the patch of a slice is issued during taps 0..5 of the slice before: long landed)
         if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        UMV_BARRIER();
         const int slice = step / 9, tap = step - slice * 9;
         if (step + 2 < nsteps) stage_w(step + 2, (step + 2) % 3);
         else {      // (keep three pieces per step to the end)
