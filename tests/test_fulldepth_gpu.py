@@ -141,3 +141,91 @@ def test_full_depth_vqa_single_request(fd):
         assert ref[0, pred] >= ref[0, ref_pred] - 2 * d - 1e-3
     print(f"full depth B=1 ctx 1060: {steps} teacher-forced steps, worst |logit diff| {worst:.4f}, worst cosine {worst_cos:.6f}, "
           f"{exact} ids with a decisive margin checked exactly")
+
+
+@pytest.fixture(scope="module")
+def fdg():
+    """the full-depth model with BOTH experts (und + gen) and the image head - 29 GB of bf16 weights on each side"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from oracle.unimedvl_cpu import OracleBagel
+    from unimedvl_amd import shapes
+    from unimedvl_amd.bagel import Bagel
+    from unimedvl_amd.config import UniMedVLConfig
+    from unimedvl_amd.weights import random_getter
+    cfg = UniMedVLConfig()
+    assert cfg.layers == 28 and cfg.hidden == 3584
+    dev = torch.device("cuda", 0)
+    get = random_getter(cfg, dev, seed=5656)
+    names = [n for n in shapes.all_shapes(cfg) if not n.startswith("vit_model.") and "connector" not in n and "vit_pos_embed" not in n]
+    sd = {name: get(name) for name in names}
+    g = torch.Generator(device=dev).manual_seed(57)
+    for k, v in sd.items():
+        if v.dim() == 1 and "norm" in k and k.endswith("weight"):
+            sd[k] = (1.0 + 0.1 * torch.randn(v.shape, device=dev, generator=g)).to(BF16)
+    model = Bagel(cfg, lambda n: sd[n], device=dev, visual_gen=True, visual_und=False)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    oracle = OracleBagel(cfg.to_dict(), {k: v.cpu() for k, v in sd.items()}, None, attn_impl="flash")
+    del sd
+    torch.cuda.empty_cache()
+    ntid = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
+    return model, oracle, cfg, ntid
+
+
+def test_full_depth_t2i_guided_flow_single_request(fdg):
+    """The GENERATION path at full depth: a 32-token prompt through the 28 `und` layers, then Bagel.generate_image
+    (bagel.py:901-1207) for one 128 x 128 image - 64 latent tokens through the 28 MoT layers of the `gen` expert, the two
+    marker tokens through the `und` expert, timestep / position embedders, llm2vae, dual classifier-free guidance with global
+    renorm - 4 timesteps = 3 Euler steps (2 guided with three contexts + 1 plain), against the CPU oracle on the same weights,
+    prompt and initial noise.  What the 2-layer full-width test (tests/test_fullwidth_gpu.py configs[2]) cannot show is how
+    the velocity error compounds over 28 layers and 3 steps; it is printed next to its bound."""
+    from copy import deepcopy
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    model, oracle, cfg, ntid = fdg
+    hw, steps = 128, 4
+    g = torch.Generator().manual_seed(58)
+    prompt = torch.randint(1000, 150000, (32,), generator=g).tolist()
+    gen = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_prompts([0], [0], ["p"], IdTok(prompt), ntid)
+    gen = model.forward_cache_update_text(gen, **gi)
+    cfg_text, cfg_img = NaiveCache(cfg.layers), deepcopy(gen)
+    og = KVCache(cfg.layers, 1)
+    okv, orope = oracle.update_text(og, [0], [0], [[ntid["bos_token_id"]] + prompt + [ntid["eos_token_id"]]])
+    assert okv == kvl == [34] and orope == rope
+    torch.manual_seed(59)
+    gl = model.prepare_vae_latent(kvl, rope, [(hw, hw)], ntid)
+    gt = model.prepare_vae_latent_cfg([0], [0], [(hw, hw)])
+    gim = model.prepare_vae_latent_cfg(kvl, rope, [(hw, hw)])
+    noise = gl["packed_init_noises"].clone()
+    trace = []
+    model.generate_image(
+        past_key_values=gen, cfg_text_past_key_values=cfg_text, cfg_img_past_key_values=cfg_img, num_timesteps=steps,
+        cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0, cfg_renorm_type="global",
+        timestep_shift=3.0, callback=lambda i, x: trace.append(x.clone()), **gl,
+        cfg_text_packed_position_ids=gt["cfg_packed_position_ids"], cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+        cfg_text_key_values_lens=gt["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+        cfg_img_packed_position_ids=gim["cfg_packed_position_ids"], cfg_img_packed_query_indexes=gim["cfg_packed_query_indexes"],
+        cfg_img_key_values_lens=gim["cfg_key_values_lens"], cfg_img_packed_key_value_indexes=gim["cfg_packed_key_value_indexes"])
+    otrace = []
+    oracle.generate_image(
+        og, [rope[0]], [(hw, hw)], noise, ntid, num_timesteps=steps, timestep_shift=3.0, cfg_interval=(0.4, 1.0), cfg_text_scale=4.0,
+        cfg_text=(KVCache(cfg.layers, 1), [0]), cfg_img_scale=1.5, cfg_img=(og.clone(), [rope[0]]), cfg_renorm_min=0.0,
+        cfg_renorm_type="global", trace=otrace)
+    assert len(trace) == len(otrace) == steps - 1
+    print("full depth, text-to-image: latent after each Euler step, engine vs oracle")
+    for i, (x, ox) in enumerate(zip(trace, otrace)):
+        d = (x.cpu().float() - ox.float()).abs()
+        rng = ox.float().abs().max().item()
+        step_size = (ox.float() - (otrace[i - 1].float() if i else noise.float())).abs().max().item()
+        print(f"  step {i}: |diff| max {d.max().item():.4f} mean {d.mean().item():.5f} (latent range {rng:.2f}, largest change of this "
+              f"step {step_size:.3f})")
+        # Measured on MI355X (round 3): |diff| max / mean = 0.026 / 0.0055, 0.062 / 0.0125, 0.142 / 0.030 after steps 0 / 1 / 2 whose
+        # largest latent changes are 0.60 / 1.16 / 2.73 (timestep_shift 3 with 4 timesteps makes the last step the big one): the
+        # deviation is a steady 4.4 - 5.3 % (max) and 0.9 - 1.1 % (mean) of what the step moves, i.e. the velocity after 28 MoT
+        # layers carries the same ~1 % mean / ~5 % worst-element error as the K / V of layer 27 in the understanding test above.
+        # Bounds: 2x measured, relative to the step's largest change.
+        assert torch.isfinite(x).all()
+        assert d.max().item() <= 0.11 * step_size and d.mean().item() <= 0.023 * step_size, \
+            f"step {i}: latent max {d.max().item()} mean {d.mean().item()} vs largest change {step_size}"
+    assert gen.lens == cfg_img.lens == kvl and cfg_text.seq_lens == 0, "flow passes must not commit KV"
