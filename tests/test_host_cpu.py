@@ -200,6 +200,9 @@ def test_kernel_policy_queries_need_no_gpu():
     # the bench's prefill / ViT / flow shapes go to the hand-interleaved 256x256 tile
     for M, N, K in ((8208, 4608, 3584), (8208, 37888, 3584), (8208, 3584, 18944), (8192, 3456, 1152), (2064, 37888, 3584)):
         assert lib.umv_gemm_tile_config(M, N, K) == 266, (M, N, K)
+    assert lib.umv_gemm_tile_config(8192, 1152, 4304) == 288        # ViT fc2 / out-proj: 4 x 288 columns x 64 row blocks = 256 tiles
+    assert lib.umv_gemm_tile_config(2048, 4608, 3584) == 288        # guided flow pass q/k/v
+    assert lib.umv_gemm_tile_config(32768, 1152, 4304) == 384       # 32 images: 768 tiles of 384 x 128 = 3 full rounds
     assert lib.umv_gemm_tile_config(1026, 4608, 3584) == 268        # one image span: 256(n) x 128(m)
     assert lib.umv_gemm_tile_config(1026, 3584, 3584) == 270        # 128 x 128, two workgroups per CU
     assert lib.umv_gemm_tile_config(300, 1152, 608) == 64           # short K

@@ -92,8 +92,9 @@ TILED = [
     (8208, 37888, 3584, "swiglu", 266),       # gate/up SwiGLU
     (8192, 3456, 1152, "bias", 266),          # ViT fused q/k/v
     (8192, 4304, 1152, "gelu", 384),          # ViT fc1 + GELU-tanh: 12 x 384 columns (the last block ragged)
-    (8192, 1152, 4304, "residual", 384),      # ViT fc2 (+ residual): 3 x 384 columns, no padding
-    (8192, 1152, 1152, "residual", 384),      # ViT out-proj
+    (8192, 1152, 4304, "residual", 288),      # ViT fc2 (+ residual): 4 x 288 columns by 64 row blocks = 256 tiles (round 3)
+    (8192, 1152, 1152, "residual", 288),      # ViT out-proj
+    (2048, 4608, 3584, "bias", 288),          # guided flow pass QKV (2 x 1024 latent rows): 16 x 288 columns by 16 row blocks
     (2064, 4608, 3584, "bias", 384),          # flow-pass QKV: 12 x 384 columns by 17 row blocks
     (32768, 1152, 4304, "bias", 384),         # 32 images
     (2064, 37888, 3584, "swiglu", 266),       # flow pass gate/up
@@ -140,7 +141,7 @@ def test_gemm_tiled_branch(ops, M, N, K, epi, cfg):
     check_bf16(out, ref, 1, 0.98, f"{epi} {M}x{N}x{K}", two_roundings=(epi == "gelu"))
 
 
-@pytest.mark.parametrize("M,n_text,N,K,cfg", [(2064, 16, 4608, 3584, 384), (8224, 16, 4608, 3584, 266), (2064, 16, 3584, 18944, 268), (1032, 8, 4608, 3584, 268)])
+@pytest.mark.parametrize("M,n_text,N,K,cfg", [(2064, 16, 4608, 3584, 288), (2080, 16, 4608, 3584, 384), (8224, 16, 4608, 3584, 266), (2064, 16, 3584, 18944, 268), (1032, 8, 4608, 3584, 268)])
 def test_gemm_tiled_row_indexed_mot(ops, M, n_text, N, K, cfg):
     """MoT routing at flow-pass size (qwen2_navit.py:552-562,891-898): the latent rows go through the tiled kernel by a row
     index list, the marker-token rows through the weight-streaming kernel, into one output buffer."""
@@ -193,7 +194,8 @@ def test_gemm_splitk_partials_sum_to_fp32_reference(ops, M, N, K, S):
     check_bf16(got.to(BF16), ref.to(BF16), 1, 0.98, "split-K")
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(300, 100, 2048, 266), (515, 1000, 1152, 268), (1000, 4300, 1152, 266), (777, 250, 1024, 270)])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 100, 2048, 266), (515, 1000, 1152, 268), (1000, 4300, 1152, 266), (777, 250, 1024, 270),
+                                          (515, 1000, 1160, 288), (130, 300, 3584, 288)])   # 288 x 128: 26 staging pieces on 8 waves
 def test_gemm_lds_epilogue_ragged_and_unaligned(ops, M, N, K, tile, monkeypatch):
     """The whole-row LDS epilogue of the tiled kernels (gemm_epilogue.h::epi_wave_tile_lds) on everything that leaves its 16-byte
     fast path: N not a multiple of 8 (the last 16-byte chunk of a row is partial), an output / residual row pitch that is not a

@@ -720,10 +720,16 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;      // 1 KiB fragment tiles per k-step
-    constexpr int TPW = (WTILES + XTILES) / NW;                          // tiles staged per wave per k-step
-    static_assert((WTILES + XTILES) % NW == 0, "staging tiles must divide evenly over the waves");
-    constexpr int BUF = (WTILES + XTILES) * 1024;
+    constexpr int NT_ALL = WTILES + XTILES;
+    constexpr int TPW = (NT_ALL + NW - 1) / NW;                          // tiles staged per wave per k-step
+    // A tile whose 1 KiB pieces do not divide evenly over the waves (288 x 128: 26, 224 x 128: 22) rounds TPW up: the surplus
+    // slots copy the zero page into a spare KiB each behind the buffers, so that every wave issues the same number of
+    // LDS-DMA pieces per k-step and the counted s_waitcnt vmcnt(N) below stay exact.
+    constexpr int NDUMMY = NW * TPW - NT_ALL;
+    constexpr int BUF = NT_ALL * 1024;
+    constexpr int DUMPOFF = NBUF * BUF + (BN * 2 + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];        // [NBUF][BUF]: W tiles [BN/16][KTS], then x tiles [BM/16][KTS]
+    auto dst_of = [&](int buf, int f) -> char* { return (NDUMMY == 0 || f < NT_ALL) ? smem + buf * BUF + f * 1024 : smem + DUMPOFF + (f - NT_ALL) * 1024; };
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -781,6 +787,9 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             const int nt = nt_blk + tl;
             tvalid[i] = nt < NTT;
             src[i] = a.wp + ((int64_t)(tvalid[i] ? nt : 0) * KT + kt0 + kk) * 512 + lane * 8;
+        } else if (NDUMMY != 0 && f >= NT_ALL) {
+            tvalid[i] = false;                      // surplus slot: zero page, zero bump
+            src[i] = reinterpret_cast<const bf16_t*>(g_zero_page);
         } else {
             const int fx = f - WTILES;
             const int tl = fx / KTS, kk = fx % KTS;
@@ -813,12 +822,14 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                 if (f < WTILES) {
                     const int kt = step * KTS + f % KTS;
                     p = (tvalid[i] && kt < KTL) ? src[i] + (int64_t)step * (KTS * 512) : zero;
+                } else if (NDUMMY != 0 && f >= NT_ALL) {
+                    p = zero;
                 } else {
                     const int kt = step * KTS + (f - WTILES) % KTS;
                     const int k = (kt0 + kt) * 32 + g * 8;
                     p = (kt < KTL && k < a.K) ? src[i] + (int64_t)step * (KTS * 32) : zero;
                 }
-                char* dst = smem + buf * BUF + f * 1024;
+                char* dst = dst_of(buf, f);
                 __builtin_amdgcn_global_load_lds((const void*)p, (lds_ptr_t)dst, 16, 0, 0);
             }
             return;
@@ -826,7 +837,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int f = wave * TPW + i;
-            char* dst = smem + buf * BUF + f * 1024;
+            char* dst = dst_of(buf, f);
             __builtin_amdgcn_global_load_lds((const void*)cur[i], (lds_ptr_t)dst, 16, 0, 0);
             cur[i] += bump[i];
         }
@@ -843,7 +854,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         else if (SCHED == 1) {       // (K < 96) keep the number of pieces in flight uniform: see the interleaved loop below
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
-                __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_t)(smem + p * BUF + (wave * TPW + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_t)dst_of(p, wave * TPW + i), 16, 0, 0);
         }
     }
     if constexpr (SCHED == 1) {
@@ -905,6 +916,8 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                     if (f < WTILES) {
                         const int kt = st * KTS + f % KTS;
                         cur[i] = (tvalid[i] && kt < KTL) ? src[i] + (int64_t)st * (KTS * 512) : zero;
+                    } else if (NDUMMY != 0 && f >= NT_ALL) {
+                        cur[i] = zero;
                     } else {
                         const int kt = st * KTS + (f - WTILES) % KTS;
                         const int k = (kt0 + kt) * 32 + g * 8;
@@ -913,7 +926,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                     bump[i] = 0;
                 }
             }
-            char* dma_dst = smem + (st % NBUF) * BUF + wave * TPW * 1024;
+            const int dma_buf = st % NBUF;
             // the reads of the last step fetch a tile nobody uses (the buffer exists): no branch inside the sequence
             const uint32_t nb = lds0 + ((step + 1) % NBUF) * BUF;
             const uint32_t wa = nb + woff, xa = nb + xoff;
@@ -926,7 +939,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                 constexpr int pc = dma_slot(i, NMMA, TPW);          // the DMA piece (if any) that follows MFMA i
                 if constexpr (pc >= 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_global_load_lds((const void*)cur[pc], (lds_ptr_t)(dma_dst + pc * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const void*)cur[pc], (lds_ptr_t)dst_of(dma_buf, wave * TPW + pc), 16, 0, 0);
                     cur[pc] += bump[pc];
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1037,7 +1050,9 @@ static int raster_gn() {   // n-blocks per strip of the tile order; UMV_GEMM_RAS
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
-    constexpr size_t lds = (size_t)NBUF * (BN / 16 * KTS + BM / 16 * KTS) * 1024 + BN * 2;   // staging buffers + the tile's bias
+    constexpr int NT_ALL = BN / 16 * KTS + BM / 16 * KTS, NWV = WN * WM;
+    constexpr size_t lds = (size_t)NBUF * NT_ALL * 1024 + (BN * 2 + 15) / 16 * 16      // staging buffers + the tile's bias
+                           + (size_t)((NT_ALL + NWV - 1) / NWV * NWV - NT_ALL) * 1024;   // + a spare KiB per surplus staging slot
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[UMV_MAX_DEVICES] = {};
     if (umv_first_on_device(attr_set)) {
@@ -1078,7 +1093,7 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
 // 4-buffer tile with the interleaved schedule wins whenever it yields >= ~144 workgroups (885-1120 TF/s on the
 // prefill / flow / ViT shapes); below that the 256(n) x 128(m) interleaved tile (M ~ 2048: 920-1020 TF/s), then
 // 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
-// UMV_GEMM_TILE=<256|266|258|268|384|129|130|270|64> overrides (tuning only).
+// UMV_GEMM_TILE=<256|266|258|268|384|288|129|130|270|64> overrides (tuning only).
 // Exported so that tests can assert which kernel a shape is sent to (returns 0 for M <= 64: weight-streaming kernels).
 extern "C" int umv_gemm_tile_config(int M, int N, int K) {
     static int force = -1;
@@ -1096,6 +1111,14 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
         // 256 x 256: 76 vs 95 us)
         const long cus = 256, t384 = (long)((M + 127) / 128) * ((N + 383) / 384);
         const long c266 = (wg256 + cus - 1) / cus * 65536, c384 = (t384 + cus - 1) / cus * 49152;
+        // 288 x 128 (round 3): N = 1152 / 4608 = 4 / 16 x 288 columns give exactly 256 tiles at 8192 / 2048 rows where 384 x 128 fills
+        // 192 of the 256 CUs.  Its 18 MFMAs per k-step carry the same per-step overhead as the bigger tiles' 24 - 32 (about 0.8 of
+        // their rate per unit of tile area), so it has to win by more than that: out-proj 38.4 -> 34.8 us, fc2 91.9 -> 85.4, the
+        // flow passes' q/k/v GEMM (2048 x 4608 x 3584) 80.2 -> 73.8
+        if (N % 288 == 0) {
+            const long t288 = (long)((M + 127) / 128) * (N / 288), c288 = (t288 + cus - 1) / cus * 36864;
+            if (c288 * 6 < c384 * 5 && c288 * 6 < c266 * 5) return 288;
+        }
         if (c384 * 10 < c266 * 9) return 384;
     }
     if (wg256 >= 144) return 266;
@@ -1192,6 +1215,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 256) return launch_tiled<2, 4, 8, 4, 1, 4>(a, KT, NTT, s);      // 256x256x32, 4 buffers (128 KiB)
     if (cfg == 129) return launch_tiled<2, 2, 4, 4, 2, 2>(a, KT, NTT, s);      // 128x128x64, 2 buffers (64 KiB, 2 WG/CU)
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
+    if (cfg == 288) return launch_tiled<2, 4, 9, 2, 1, 4, 1>(a, KT, NTT, s);   // 288(n)x128(m)x32: N = 1152 / 4608 = 4 / 16 x 288 -> 256 tiles at 8192 / 2048 rows
     if (cfg == 266) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, MFMA / ds_read interleaved by hand
     if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
     if (cfg == 384) return launch_tiled<4, 2, 6, 4, 1, 4, 1>(a, KT, NTT, s);   // 384(n)x128(m)x32, 8 waves of 96 x 64: N = 1152 = 3 x 384 without padding
