@@ -1104,7 +1104,9 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
     const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long wg258 = (long)((M + 127) / 128) * ((N + 255) / 256);
     if (K < 1024) return 64;              // short K: the 4-buffer prologue does not amortise
-    if (wg256 >= 144 && N <= 8192) {      // (wide N: many n-blocks either way, 256 x 256 wins or ties - 2064 x 37888: 602 vs 606 us)
+    if (wg256 >= 144 && (N <= 8192 || M <= 1024)) {   // (wide N: many n-blocks either way, 256 x 256 wins or ties - 2064 x 37888: 602 vs 606 us -
+                                                      // except at few rows: a single image's guided flow pass, 512 x 37888 x 3584, is 296 tiles = two
+                                                      // rounds of 256 x 256 against two rounds of the smaller 384 x 128: 231 -> 206 us)
         // N = 1152 (SigLIP out / fc2) is 4.5 tiles of 256: 10 % padding and 160 tiles for 256 CUs.  As 3 x 384 columns by 128 rows
         // it is 192 tiles of 3/4 the work: rounds x tile area decides (out 46.7 -> 37.3 us, fc2 103.8 -> 89.9, fc1 (N = 4304: 544
         // tiles = 2.1 rounds against 768 = 3 rounds of 3/4) 120.3 -> 111.7; the fused q/k/v GEMM, N = 3456, stays on
