@@ -190,6 +190,18 @@ def test_checkpoint_overlay_and_bf16_preference(tmp_path):
         SafetensorsGetter(str(base / "ema.safetensors"), {"a.weight": (3, 2)})("a.weight")
     with pytest.raises(FileNotFoundError):
         find_weights_file(str(tmp_path / "nothing"))
+    # the reference's conversion utility (interactive_vqa_inferencer.py:93-114), kept as a method of both entry-point classes
+    from safetensors.torch import load_file
+    from unimedvl_amd.interactive_image_generator import ImageGenerator
+    from unimedvl_amd.interactive_vqa_inferencer import VQAInferencer
+    src, dst = str(ft / "ema.safetensors"), str(ft / "ema_bf16.safetensors")
+    assert VQAInferencer().convert_checkpoint_to_bf16(str(ft / "missing.safetensors"), dst) is False
+    assert VQAInferencer().convert_checkpoint_to_bf16(src, dst) is True
+    out = load_file(dst)
+    assert out["a.weight"].dtype == torch.bfloat16 and float(out["a.weight"][1, 2]) == 7.0
+    dst2 = str(ft / "copy_bf16.safetensors")
+    assert ImageGenerator().convert_checkpoint_to_bf16(dst, dst2) is True          # already bf16: copied
+    assert load_file(dst2)["a.weight"].dtype == torch.bfloat16
 
 
 def test_kernel_policy_queries_need_no_gpu():

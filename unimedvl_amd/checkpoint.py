@@ -21,6 +21,27 @@ def find_weights_file(model_path, use_model_checkpoint=False):
     raise FileNotFoundError(f"no {base}(_bf16).safetensors under {model_path}")
 
 
+def convert_checkpoint_to_bf16(input_path, output_path):
+    """The reference's one-time conversion utility (interactive_vqa_inferencer.py:93-114 / interactive_image_generator.py:97-118),
+    kept for callers that use it directly: write `output_path` = the tensors of `input_path` in bf16.  False when the input does
+    not exist, True otherwise (an input that already is bf16 - judged by its first tensor, as the reference does - is copied).
+    The engine itself does not need the file: it casts on the way to the device and keeps its own packed fast-path file."""
+    import shutil
+    if not os.path.exists(input_path):
+        return False
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    with safe_open(input_path, framework="pt", device="cpu") as f:
+        names = list(f.keys())
+        if names and f.get_tensor(names[0]).dtype == torch.bfloat16:
+            if input_path != output_path:
+                shutil.copy(input_path, output_path)
+            return True
+        out = {k: f.get_tensor(k).to(torch.bfloat16) for k in names}     # every tensor, as the reference (tensor.to(bfloat16))
+    save_file(out, output_path)
+    return True
+
+
 class SafetensorsGetter:
     """get(name) over one safetensors file; validates shapes against the expected table."""
 

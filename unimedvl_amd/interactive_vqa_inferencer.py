@@ -77,6 +77,11 @@ class VQAInferencer:
         if torch.cuda.is_available():
             torch.cuda.manual_seed_all(seed)
 
+    def convert_checkpoint_to_bf16(self, input_path, output_path):
+        """reference method of the same name (one-time fp32 -> bf16 checkpoint conversion); not needed by load_model() here"""
+        from .checkpoint import convert_checkpoint_to_bf16
+        return convert_checkpoint_to_bf16(input_path, output_path)
+
     def load_model(self, model=None, tokenizer=None, new_token_ids=None):
         """Builds the engine from ``config['model_path']``.  Pre-built objects may be injected
         (tests / benches without a checkpoint)."""
