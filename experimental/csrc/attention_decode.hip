@@ -20,7 +20,7 @@
 
 #include "common.h"
 #include "attention_combine.h"
-#include "../../include/unimedvl_hip_experimental.h"
+#include "unimedvl_hip_experimental.h"
 
 __device__ __forceinline__ bf16x8 adec_mask_keys(bf16x8 v, int nvalid) {
     bf16x8 o;

@@ -18,8 +18,8 @@
 // Per q column the arithmetic does not depend on NW or on what the other columns hold: results are bit-identical across
 // the variants and independent of the batch composition.
 #include "common.h"
-#include "../../include/unimedvl_hip.h"
-#include "../../include/unimedvl_hip_experimental.h"
+#include "unimedvl_hip.h"
+#include "unimedvl_hip_experimental.h"
 #include <stdlib.h>
 #include <type_traits>
 

@@ -27,7 +27,7 @@
 // garbage instead of hanging), issues ONE agent-scope acquire (buffer_inv sc1) and only then reads.
 // Counters are zeroed by the host before every launch (umv_decode_engine does it with a memset node on the stream).
 #include "common.h"
-#include "../../include/unimedvl_hip_experimental.h"
+#include "unimedvl_hip_experimental.h"
 #include "gemm_epilogue.h"
 #include <stdlib.h>
 

@@ -15,7 +15,7 @@
 // Work split and summation order are those of gemm_skinny_kernel (8 contiguous K slices in wave order), so for the
 // same x the results are bit-identical to umv_gemm_bf16 / umv_gemm_fp8w.
 #include "common.h"
-#include "../../include/unimedvl_hip_experimental.h"
+#include "unimedvl_hip_experimental.h"
 #include "gemm_epilogue.h"
 
 #define DG_WAVES 8

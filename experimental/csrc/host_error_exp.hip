@@ -1,4 +1,4 @@
-// Error plumbing of the C ABI (host side): one thread-local message, read through umv_last_error().
+// Error plumbing of libunimedvl_hip_experimental.so (host side): one thread-local message, read through umv_exp_last_error().
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -10,5 +10,4 @@ void umv_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-extern "C" const char* umv_last_error(void) { return g_err; }
-extern "C" int umv_version(void) { return 102; }
+extern "C" const char* umv_exp_last_error(void) { return g_err; }

@@ -2,7 +2,7 @@
 // memory-side cache is not delivered faster than HBM delivers it, and a prefetch branch on a second stream made the decode
 // graph slower.
 #include "common.h"
-#include "../../include/unimedvl_hip_experimental.h"
+#include "unimedvl_hip_experimental.h"
 
 // ----------------------------------------------------------------------------- weight prefetch into L2 / Infinity Cache
 // Decode is a chain of dependent kernels; during the latency-bound ones (norms, RoPE/KV append,

@@ -11,13 +11,15 @@ This module only builds the op tables (device memory, read with scalar loads) an
 
 EXPERIMENTAL: bit-identical to the kernel chain (tests/test_decode_engine_gpu.py) but slower on MI355X (116 vs 93 us per layer
 for these ops) - every hand-off between workgroups costs 3-4 loaded memory round trips.  It lives in
-libunimedvl_hip_experimental.so and is not wired into decode.py.
+experimental/lib/libunimedvl_hip_experimental.so and is not wired into decode.py.
 """
 import ctypes as C
 
 import torch
 
-from . import _lib, ops
+from unimedvl_amd import ops
+
+from . import _lib
 from ._lib import DeOp
 
 BF16 = torch.bfloat16
@@ -98,14 +100,14 @@ class EngineProgram:
         self.dummy = torch.zeros(512, dtype=BF16, device=device)
 
     def launch(self, trace=None):
-        lib = _lib.load_experimental()
+        lib = _lib.load()
         cnt = self.counters.buf if self.counters is not None else None
         if trace is not None:      # tuning only: [grid][64] int64 timeline of the lead service waves
-            _lib.check_exp(lib.umv_decode_engine_traced(self.table.data_ptr(), self.n, self.M, _ptr(cnt), 0 if cnt is None else cnt.numel(),
+            _lib.check(lib.umv_decode_engine_traced(self.table.data_ptr(), self.n, self.M, _ptr(cnt), 0 if cnt is None else cnt.numel(),
                                                self.err.data_ptr(), self.dummy.data_ptr(), self.grid, trace.data_ptr(), ops._stream()),
                   "umv_decode_engine_traced")
             return
-        _lib.check_exp(lib.umv_decode_engine(self.table.data_ptr(), self.n, self.M, _ptr(cnt), 0 if cnt is None else cnt.numel(),
+        _lib.check(lib.umv_decode_engine(self.table.data_ptr(), self.n, self.M, _ptr(cnt), 0 if cnt is None else cnt.numel(),
                                     self.err.data_ptr(), self.dummy.data_ptr(), self.grid, ops._stream()), "umv_decode_engine")
 
     def check_error(self):

@@ -11,14 +11,15 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "unimedvl_hip.h")
-EXP_HEADER = os.path.join(ROOT, "include", "unimedvl_hip_experimental.h")
+EXP_HEADER = os.path.join(ROOT, "experimental", "include", "unimedvl_hip_experimental.h")
+INCLUDE = os.path.join(ROOT, "include")
 
-PAIRS = {   # C struct -> ctypes class name in unimedvl_amd._lib
+PAIRS = {   # C struct -> ctypes class name in unimedvl_amd._lib (the last three: experimental._lib)
     "umv_gemm_args": "GemmArgs",
     "umv_qkv_post_args": "QkvPostArgs",
     "umv_attn_args": "AttnArgs",
-    "umv_attn_decode_args": "AttnDecodeArgs",
     "umv_gemm8_args": "Gemm8Args",
+    "umv_attn_decode_args": "AttnDecodeArgs",
     "umv_decode_layout": "DecodeLayout",
     "umv_de_op": "DeOp",
 }
@@ -41,6 +42,7 @@ def _c_fields(struct):
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
 def test_ctypes_structs_match_the_header(tmp_path):
+    from experimental import _lib as xlib
     from unimedvl_amd import _lib
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', f'#include "{EXP_HEADER}"', "int main(void) {"]
     for cs in PAIRS:
@@ -51,14 +53,14 @@ def test_ctypes_structs_match_the_header(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text("\n".join(lines))
     exe = tmp_path / "abi"
-    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    subprocess.check_call(["gcc", "-std=c11", f"-I{INCLUDE}", "-o", str(exe), str(src)])
     out = subprocess.check_output([str(exe)], text=True)
     c = {}
     for ln in out.splitlines():
         s, f, v = ln.split()
         c.setdefault(s, {})[f] = int(v)
     for cs, pyname in PAIRS.items():
-        cls = getattr(_lib, pyname)
+        cls = getattr(_lib, pyname, None) or getattr(xlib, pyname)
         assert ctypes.sizeof(cls) == c[cs]["size"], f"{cs}: sizeof {c[cs]['size']} in C, {ctypes.sizeof(cls)} in ctypes"
         py_fields = [n for n, _ in cls._fields_]
         assert py_fields == _c_fields(cs), f"{cs}: field order differs\n C : {_c_fields(cs)}\n py: {py_fields}"
@@ -69,9 +71,10 @@ def test_ctypes_structs_match_the_header(tmp_path):
 def test_ctypes_signatures_match_the_header():
     """Every function the header declares is bound in _lib._SIGS with the same number of parameters, pointer parameters as
     pointers / void*, 64-bit integers as 64-bit, floats as floats."""
+    from experimental import _lib as xlib
     from unimedvl_amd import _lib
     _check_signatures(HEADER, _lib._SIGS, 38)
-    _check_signatures(EXP_HEADER, _lib._EXP_SIGS, 8)
+    _check_signatures(EXP_HEADER, xlib._EXP_SIGS, 8)
 
 
 def _check_signatures(header, sigs, at_least):

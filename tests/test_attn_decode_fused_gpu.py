@@ -1,4 +1,4 @@
-"""umv_attn_decode_fused (q/k RMSNorm + RoPE + KV append folded into the decode attention) against the two-kernel path
+"""umv_attn_decode_fused (EXPERIMENTAL, experimental/csrc/attention_decode.hip: q/k RMSNorm + RoPE + KV append folded into the decode attention) against the two-kernel path
 umv_qkv_post + umv_attn_varlen it replaces, through the C ABI.  Both run the same MFMAs on the same operands; only the
 row sum of squares of the q/k norms is accumulated in another order, so: V^T column bit-exact, K row / attention output
 within 1 bf16 ulp of the value and >= 99 % / 97 % bit-identical.  Ragged lengths put the new key at every position of a
@@ -8,6 +8,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
+
+
+def _xops():
+    """the experimental package (experimental/): skip when its library has not been built (python -m experimental.build)"""
+    from experimental import _lib as xlib
+    if not xlib.available():
+        pytest.skip("experimental library not built (python -m experimental.build)")
+    from experimental import ops as xops
+    return xops
 
 
 def _ops():
@@ -51,7 +60,7 @@ def test_fused_decode_attention_matches_two_kernel_path(nsplit):
     ops.attention(q, ref, ref_slab, cu, kv_len, nq, nkv, hd, True, 1, cap, nsplit, ws)
     got_slab = fresh()
     got = torch.zeros(B, nq * hd, dtype=BF16, device="cuda")
-    ops.attn_decode_fused(qkv, got, got_slab, cu, kv_len, pos, nq, nkv, hd, 1e-6, qn, kn, cos, sin, nsplit, ws)
+    _xops().attn_decode_fused(qkv, got, got_slab, cu, kv_len, pos, nq, nkv, hd, 1e-6, qn, kn, cos, sin, nsplit, ws)
     torch.cuda.synchronize()
     assert torch.equal(got_slab.vt, ref_slab.vt), "V^T column"
     dk = (got_slab.k.float() - ref_slab.k.float()).abs()
@@ -99,7 +108,7 @@ def test_fused_decode_attention_from_splitk_partials(n_splits, with_bias):
         slab.k.copy_(hist_k)
         slab.vt.copy_(hist_v)
         out = torch.zeros(B, nq * hd, dtype=BF16, device="cuda")
-        ops.attn_decode_fused(None if kw else qkv, out, slab, cu, kv_len, pos, nq, nkv, hd, 1e-6, qn, kn, cos, sin, nsplit, ws, **kw)
+        _xops().attn_decode_fused(None if kw else qkv, out, slab, cu, kv_len, pos, nq, nkv, hd, 1e-6, qn, kn, cos, sin, nsplit, ws, **kw)
         torch.cuda.synchronize()
         outs.append((out, slab.k.clone(), slab.vt.clone()))
     for a, b in zip(outs[0], outs[1]):

@@ -1,5 +1,5 @@
-"""EXPERIMENTAL prefill attention on the 32x32x16 matrix instruction (csrc/attention_prefill32.hip, umv_attn_prefill32 of
-libunimedvl_hip_experimental.so): the hd 128 shapes of the product path - image-span prefill, ragged causal prefill on cached
+"""EXPERIMENTAL prefill attention on the 32x32x16 matrix instruction (experimental/csrc/attention_prefill32.hip, umv_attn_prefill32 of
+experimental/lib/libunimedvl_hip_experimental.so): the hd 128 shapes of the product path - image-span prefill, ragged causal prefill on cached
 context, a guided flow pass, a single segment (flash_attn_varlen_func at qwen2_navit.py:605-614) - against the fp32 flash model of
 tests/test_kernel_branches_gpu.py and against the shipped kernel, plus what the kernel promises about itself: 4 and 8 waves
 per workgroup give the same bits, and a segment computed alone equals the same segment inside a batch."""
@@ -13,6 +13,15 @@ import torch
 from test_kernel_branches_gpu import BF16, _attn_ref, check_bf16, rnd  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+
+
+def _xops():
+    """the experimental package (experimental/): skip when its library has not been built (python -m experimental.build)"""
+    from experimental import _lib as xlib
+    if not xlib.available():
+        pytest.skip("experimental library not built (python -m experimental.build)")
+    from experimental import ops as xops
+    return xops
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,7 +33,11 @@ def ops():
     return o
 
 
-def _run(ops, nq, nkv, hd, q_lens, k_lens, causal, seed, experimental32=True):
+def _attn32(ops, *a):
+    return _xops().attn_prefill32(*a)
+
+
+def _run(ops, nq, nkv, hd, q_lens, k_lens, causal, seed):
     nseg = len(q_lens)
     cap = (max(k_lens) + 31) // 32 * 32
     slab = ops.KVSlab(nseg, nkv, cap, hd, "cuda")
@@ -39,8 +52,7 @@ def _run(ops, nq, nkv, hd, q_lens, k_lens, causal, seed, experimental32=True):
         slab.vt[i, :, :, :lk] = vs[i].permute(1, 2, 0)
     cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32).cuda()
     out = torch.zeros((T, nq, hd), dtype=BF16, device="cuda")
-    ops.attention(q, out, slab, cu, torch.tensor(k_lens, dtype=torch.int32).cuda(), nq, nkv, hd, causal, max(q_lens), max(k_lens),
-                  experimental32=experimental32)
+    _attn32(ops, q, out, slab, cu, torch.tensor(k_lens, dtype=torch.int32).cuda(), nq, nkv, hd, causal, max(q_lens), max(k_lens))
     return out, _attn_ref(q, ks, vs, q_lens, causal)
 
 
@@ -74,15 +86,15 @@ def test_prefill32_segment_alone_equals_segment_in_batch(ops):
     cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32).cuda()
     kvl = torch.tensor(k_lens, dtype=torch.int32).cuda()
     out = torch.zeros_like(q)
-    ops.attention(q, out, slab, cu, kvl, 28, 4, 128, True, max(q_lens), max(k_lens), experimental32=True)
+    _attn32(ops, q, out, slab, cu, kvl, 28, 4, 128, True, max(q_lens), max(k_lens))
     for i in (1, 3):
         s1 = ops.KVSlab(1, 4, cap, 128, "cuda")
         s1.k.copy_(slab.k[i:i + 1])
         s1.vt.copy_(slab.vt[i:i + 1])
         qi = q[int(cu[i]):int(cu[i + 1])].contiguous()
         oi = torch.zeros_like(qi)
-        ops.attention(qi, oi, s1, torch.tensor([0, q_lens[i]], dtype=torch.int32).cuda(), kvl[i:i + 1].contiguous(), 28, 4, 128, True,
-                      q_lens[i], k_lens[i], experimental32=True)
+        _attn32(ops, qi, oi, s1, torch.tensor([0, q_lens[i]], dtype=torch.int32).cuda(), kvl[i:i + 1].contiguous(), 28, 4, 128, True,
+                q_lens[i], k_lens[i])
         assert torch.equal(oi, out[int(cu[i]):int(cu[i + 1])])
 
 

@@ -1,4 +1,4 @@
-"""Decode layer engine (experimental; unimedvl_amd/engine.py, csrc/decode_engine.hip): one persistent launch for
+"""Decode layer engine (EXPERIMENTAL; experimental/engine.py, experimental/csrc/decode_engine.hip): one persistent launch for
 o_proj + residual -> RMSNorm -> gate/up + SwiGLU -> down_proj (8 K groups) -> sum + residual -> RMSNorm -> q/k/v_proj
 (qwen2_navit.py:617-620,873-898,541-543; modeling_qwen2.py:234-235) must reproduce the kernel chain of decode.py::_step
 bit for bit at the full widths - every value crosses workgroups through the in-launch hand-off protocol (write-through
@@ -7,6 +7,15 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def _xops():
+    """the experimental package (experimental/): skip when its library has not been built (python -m experimental.build)"""
+    from experimental import _lib as xlib
+    if not xlib.available():
+        pytest.skip("experimental library not built (python -m experimental.build)")
+    from experimental import ops as xops
+    return xops
 
 H, I, QKV = 3584, 18944, 4608
 EPS = 1e-6
@@ -52,7 +61,8 @@ def _classic(lw, attn, seq, B):
 
 @pytest.mark.parametrize("B", [8, 3])
 def test_engine_chain_equals_kernel_chain(layer, B):
-    from unimedvl_amd import engine
+    _xops()
+    from experimental import engine
     lw, dev, gen = layer
     act = torch.empty(B, I, dtype=BF16, device=dev)
     p_h = torch.empty(8, B, H, dtype=torch.float32, device=dev)
@@ -83,7 +93,9 @@ def test_engine_chain_equals_kernel_chain(layer, B):
 
 
 def test_engine_rejects_more_than_eight_rows(layer):
-    from unimedvl_amd import _lib, engine
+    _xops()
+    from unimedvl_amd import _lib
+    from experimental import engine
     lw, dev, gen = layer
     B = 9
     act = torch.empty(B, I, dtype=BF16, device=dev)

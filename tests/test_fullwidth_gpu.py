@@ -95,11 +95,14 @@ def _check_kv(cache, ocache, layers, rtol, what):
         _close(cache.packed_values(l), torch.cat(ocache.v[l], 0), rtol, f"{what} V layer {l}")
 
 
-def _forced_decode_check(model, oracle, cache, ocache, kvl, rope, ntid, steps, what, atol=0.25):
-    """engine: free greedy decode under the HIP graph; oracle: fed the engine's inputs step by step"""
+def _forced_decode_check(model, oracle, cache, ocache, kvl, rope, ntid, steps, what, atol=0.25, start_tokens=None):
+    """engine: free greedy decode under the HIP graph; oracle: fed the engine's inputs step by step.  start_tokens: continue a
+    previous session (its last predicted ids) instead of starting from bos."""
     from unimedvl_amd.decode import DecodeSession
     B = len(kvl)
     gi = model.prepare_start_tokens(kvl, rope, ntid)
+    if start_tokens is not None:
+        gi["packed_start_tokens"] = start_tokens.to(gi["packed_start_tokens"].dtype)
     sess = DecodeSession(model.language_model, cache, gi["packed_start_tokens"], gi["packed_query_position_ids"], steps + 1,
                          use_graph=True)
     assert sess.graph is not None and sess.sk != (1, 1, 1) and sess.nsplit > 1, "the test is meant to pin the shipped decode step"
@@ -129,6 +132,7 @@ def _forced_decode_check(model, oracle, cache, ocache, kvl, rope, ntid, steps, w
     sess.commit()
     print(f"{what}: {steps} teacher-forced steps x {B}: worst |logit diff| {worst:.4f}; {flips} near-tie flips; "
           f"{sure_checked} ids checked exactly")
+    sess.worst_logit_diff, sess.sure_checked, sess.flips = worst, sure_checked, flips
     return sess
 
 
@@ -261,6 +265,172 @@ def test_configs2_t2i_256_guided_flow_and_pixels(fw):
     q = torch.quantile(allv[torch.randperm(allv.numel())[:2_000_000]].float(), torch.tensor([0.5, 0.9, 0.99, 0.999]))
     print(f"configs[2] B=4 256x256: latent deviation over {steps - 1} Euler steps: max {worst:.4f} (bound 0.125), mean {allv.mean().item():.5f} "
           f"(bound 0.012), p50 / p90 / p99 / p99.9 = {q[0]:.4f} / {q[1]:.4f} / {q[2]:.4f} / {q[3]:.4f}")
+
+
+def _t2i_args(gl, gt, gim):
+    return dict(
+        cfg_text_packed_position_ids=gt["cfg_packed_position_ids"], cfg_text_packed_query_indexes=gt["cfg_packed_query_indexes"],
+        cfg_text_key_values_lens=gt["cfg_key_values_lens"], cfg_text_packed_key_value_indexes=gt["cfg_packed_key_value_indexes"],
+        cfg_img_packed_position_ids=gim["cfg_packed_position_ids"], cfg_img_packed_query_indexes=gim["cfg_packed_query_indexes"],
+        cfg_img_key_values_lens=gim["cfg_key_values_lens"], cfg_img_packed_key_value_indexes=gim["cfg_packed_key_value_indexes"], **gl)
+
+
+def test_configs2_t2i_256_fifty_timesteps(fw):
+    """configs[2] AS WRITTEN: 50 diffusion timesteps = 49 Euler steps (bagel.py:937-986; the default of
+    interactive_image_generator.py:63), 256 x 256, the reference's default guidance (cfg_text 4.0, cfg_img 1.5, interval (0.4, 1],
+    global renorm, shift 3.0) - VERDICT r03 "missing" #2: CFG multiplies rounding noise by up to 6 per guided step and only 5
+    timesteps had been compared.  Two samples in one packed engine batch (per-sample renorm == the reference at B = 1), each
+    against its own oracle run: the latent after EVERY Euler step, then the uint8 pixels of the full-size VAE decoder on the
+    ENGINE's final latent against the oracle's decoder on the ORACLE's final latent (the end-to-end image, inferencer.py:234-256)."""
+    from copy import deepcopy
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    model, vae, oracle, cfg, ntid = fw
+    B, hw, steps = 2, 256, 50
+    prompts = _prompts([128] * B, 18)
+    gen = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], IdTok(prompts), ntid)
+    gen = model.forward_cache_update_text(gen, **gi)
+    cfg_text, cfg_img = NaiveCache(cfg.layers), deepcopy(gen)
+    og = KVCache(cfg.layers, B)
+    okv, orope = oracle.update_text(og, [0] * B, [0] * B, [[ntid["bos_token_id"]] + p + [ntid["eos_token_id"]] for p in prompts])
+    assert okv == kvl and orope == rope
+    torch.manual_seed(21)
+    gl = model.prepare_vae_latent(kvl, rope, [(hw, hw)] * B, ntid)
+    gt = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(hw, hw)] * B)
+    gim = model.prepare_vae_latent_cfg(kvl, rope, [(hw, hw)] * B)
+    noise = gl["packed_init_noises"].clone()
+    trace = []
+    lat = model.generate_image(
+        past_key_values=gen, cfg_text_past_key_values=cfg_text, cfg_img_past_key_values=cfg_img, num_timesteps=steps,
+        cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_interval=(0.4, 1.0), cfg_renorm_min=0.0, cfg_renorm_type="global",
+        timestep_shift=3.0, callback=lambda i, x: trace.append(x.clone()), **_t2i_args(gl, gt, gim))
+    assert len(trace) == steps - 1
+    n_tok = (hw // cfg.latent_downsample) ** 2
+    for b in range(B):
+        ob = KVCache(cfg.layers, 1)
+        for l in range(cfg.layers):
+            ob.k[l], ob.v[l] = [og.k[l][b]], [og.v[l][b]]
+        otrace = []
+        olat = oracle.generate_image(
+            ob, [rope[b]], [(hw, hw)], noise[b * n_tok:(b + 1) * n_tok], ntid, num_timesteps=steps, timestep_shift=3.0,
+            cfg_interval=(0.4, 1.0), cfg_text_scale=4.0, cfg_text=(KVCache(cfg.layers, 1), [0]), cfg_img_scale=1.5,
+            cfg_img=(ob.clone(), [rope[b]]), cfg_renorm_min=0.0, cfg_renorm_type="global", trace=otrace)
+        assert len(otrace) == steps - 1
+        per_step = []
+        for i, (x, ox) in enumerate(zip(trace, otrace)):
+            d = (x[b * n_tok:(b + 1) * n_tok].cpu().float() - ox.float()).abs()
+            per_step.append((d.max().item(), d.mean().item()))
+        mx = [p[0] for p in per_step]
+        mean = [p[1] for p in per_step]
+        rng = otrace[-1].float().abs().max().item()
+        print(f"configs[2] 50 timesteps, sample {b}: latent |diff| max per step: step 1 {mx[0]:.4f}, 10 {mx[9]:.4f}, 25 {mx[24]:.4f}, "
+              f"40 {mx[39]:.4f}, 49 {mx[48]:.4f}; worst {max(mx):.4f}; mean at the last step {mean[-1]:.5f} (latent range {rng:.2f})")
+        # measured (MI355X, round 4): see DESIGN.md section 3; bounds at ~2x
+        assert max(mx) <= T2I50_LAT_MAX and mean[-1] <= T2I50_LAT_MEAN, f"sample {b}: latent max {max(mx)} mean(last) {mean[-1]}"
+        mine = lat[b] if isinstance(lat, (list, tuple)) else lat[b * n_tok:(b + 1) * n_tok]
+        px = vae.decode_tokens_to_uint8(mine, (hw, hw), model.latent_downsample, model.latent_patch_size).cpu()
+        ref = oracle.decode_image(olat[0], (hw, hw))
+        assert px.shape == ref.shape == (hw, hw, 3)
+        diff = (px.int() - ref.int()).abs()
+        dist = {k: round(100 * (diff <= k).float().mean().item(), 3) for k in (0, 1, 2, 4, 8, 16)}
+        print(f"configs[2] 50 timesteps, sample {b}: END-TO-END uint8 pixels (engine latent -> engine VAE vs oracle latent -> oracle VAE): "
+              f"% within k grey levels {dist}, max {diff.max().item()}, mean {diff.float().mean().item():.3f}")
+        assert dist[4] >= T2I50_PIX_WITHIN4 and diff.max().item() <= T2I50_PIX_MAX, f"pixels sample {b}: {dist}, max {diff.max().item()}"
+    assert gen.lens == cfg_img.lens == kvl and cfg_text.seq_lens == 0, "flow passes must not commit KV"
+
+
+# bounds of the 50-timestep test (measured distribution in DESIGN.md section 3)
+T2I50_LAT_MAX, T2I50_LAT_MEAN, T2I50_PIX_WITHIN4, T2I50_PIX_MAX = 0.5, 0.05, 90.0, 64
+
+
+def test_t2i_packed_batch_global_renorm_reference_semantics(fw):
+    """cfg_renorm_batch_semantics="reference" (VERDICT r03 "missing" #4): the reference's generate_image takes ONE norm over the
+    whole packed batch for cfg_renorm_type="global" (bagel.py:1197-1198), which couples the samples.  B = 2 packed, against the
+    oracle run on the same PACKED batch (it restates that line as written); and the default per-sample semantics must differ
+    from it (otherwise the switch tests nothing)."""
+    from copy import deepcopy
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    model, vae, oracle, cfg, ntid = fw
+    B, hw, steps = 2, 256, 6
+    prompts = _prompts([64, 128], 28)
+    gen = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], IdTok(prompts), ntid)
+    gen = model.forward_cache_update_text(gen, **gi)
+    og = KVCache(cfg.layers, B)
+    okv, orope = oracle.update_text(og, [0] * B, [0] * B, [[ntid["bos_token_id"]] + p + [ntid["eos_token_id"]] for p in prompts])
+    assert okv == kvl and orope == rope
+    torch.manual_seed(31)
+    gl = model.prepare_vae_latent(kvl, rope, [(hw, hw)] * B, ntid)
+    gt = model.prepare_vae_latent_cfg([0] * B, [0] * B, [(hw, hw)] * B)
+    gim = model.prepare_vae_latent_cfg(kvl, rope, [(hw, hw)] * B)
+    noise = gl["packed_init_noises"].clone()
+    # make the two samples' velocity norms differ a lot, so that one shared norm and two private ones cannot agree by accident
+    n_tok = (hw // cfg.latent_downsample) ** 2
+    noise[n_tok:] *= 3.0
+    gl["packed_init_noises"] = noise.clone()
+    out = {}
+    for sem in ("reference", "per_sample"):
+        trace = []
+        model.generate_image(
+            past_key_values=gen, cfg_text_past_key_values=NaiveCache(cfg.layers), cfg_img_past_key_values=deepcopy(gen),
+            num_timesteps=steps, cfg_text_scale=4.0, cfg_img_scale=1.5, cfg_interval=(0.0, 1.0), cfg_renorm_min=0.0,
+            cfg_renorm_type="global", timestep_shift=3.0, callback=lambda i, x: trace.append(x.clone()),
+            cfg_renorm_batch_semantics=sem, **_t2i_args(dict(gl, packed_init_noises=noise.clone()), gt, gim))
+        out[sem] = [x.float().cpu() for x in trace]
+    otrace = []
+    oracle.generate_image(
+        og, rope, [(hw, hw)] * B, noise, ntid, num_timesteps=steps, timestep_shift=3.0, cfg_interval=(0.0, 1.0),
+        cfg_text_scale=4.0, cfg_text=(KVCache(cfg.layers, B), [0] * B), cfg_img_scale=1.5, cfg_img=(og.clone(), list(rope)),
+        cfg_renorm_min=0.0, cfg_renorm_type="global", trace=otrace)
+    assert len(otrace) == len(out["reference"]) == steps - 1
+    worst = max((x - ox.float()).abs().max().item() for x, ox in zip(out["reference"], otrace))
+    mean = max((x - ox.float()).abs().mean().item() for x, ox in zip(out["reference"], otrace))
+    gap = (out["per_sample"][-1] - otrace[-1].float()).abs().max().item()
+    print(f"packed-batch global renorm (reference semantics), B = 2, {steps - 1} guided Euler steps: latent |diff| vs the oracle's packed "
+          f"batch max {worst:.4f} mean {mean:.5f}; the per-sample default differs from the packed reference by {gap:.3f}")
+    assert worst <= 0.25 and mean <= 0.02, f"reference batch semantics: latent max {worst} mean {mean}"
+    assert gap > 4 * worst, "per-sample and packed-batch renorm should differ visibly on this input"
+
+
+def test_configs1_long_free_running_decode_256(fw):
+    """VERDICT r03 "missing" #3: a LONG free-running greedy decode at full width (bagel.py:1262-1314 runs to 512 tokens,
+    interactive_vqa_inferencer.py:64).  B = 8, 448 x 448 + 32-token question (context 1060), 256 steps under the HIP graph in two
+    sessions of 128: the second one makes the KV slabs GROW (capacity 1280 -> 2560: NaiveCache.ensure copies the committed
+    keys into new slabs and the step is re-captured on the new addresses) and changes the key-split count of the decode
+    attention (19 -> 21 splits).  The engine decodes freely; the oracle is fed the engine's tokens, so every one of the 2048
+    greedy ids is checked (exactly, wherever the oracle's top-2 margin exceeds 0.25) and one near-tie cannot end the comparison."""
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    model, vae, oracle, cfg, ntid = fw
+    B = 8
+    images = [_synth_image(448, 448, 400 + i) for i in range(B)]
+    prompts = _prompts([32] * B, 41)
+    cache = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_vit_images([0] * B, [0] * B, images, lambda x: x, ntid)
+    cache = model.forward_cache_update_vit(cache, **gi)
+    gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTok(prompts), ntid)
+    cache = model.forward_cache_update_text(cache, **gi)
+    oc = KVCache(cfg.layers, B)
+    okv, orope = oracle.update_vit(oc, [0] * B, [0] * B, images, ntid)
+    okv, orope = oracle.update_text(oc, okv, orope, [[ntid["bos_token_id"]] + p + [ntid["eos_token_id"]] for p in prompts])
+    assert okv == kvl == [1060] * B and orope == rope
+    cap0 = cache.cap
+    s1 = _forced_decode_check(model, oracle, cache, oc, kvl, rope, ntid, 128, "long decode, steps 1-128")
+    assert cache.cap == cap0 and cache.lens == [1060 + 128] * B
+    last = s1.pred_ids[127].clone()
+    kvl2, rope2 = [k + 128 for k in kvl], [r + 128 for r in rope]
+    s1.graph = None
+    s2 = _forced_decode_check(model, oracle, cache, oc, kvl2, rope2, ntid, 128, "long decode, steps 129-256 (after slab growth)",
+                              start_tokens=last)
+    assert cache.cap > cap0, f"the second session was meant to grow the slabs ({cap0} -> {cache.cap})"
+    assert s2.nsplit != s1.nsplit, f"the second session was meant to change the key-split count ({s1.nsplit} -> {s2.nsplit})"
+    assert cache.lens == [1060 + 256] * B
+    _check_kv(cache, oc, range(cfg.layers), 2e-2, "after 256 decode steps")
+    print(f"long free-running decode: 256 steps x {B}, slab capacity {cap0} -> {cache.cap}, key splits {s1.nsplit} -> {s2.nsplit}; "
+          f"worst |logit diff| {max(s1.worst_logit_diff, s2.worst_logit_diff):.4f}; {s1.sure_checked + s2.sure_checked} of {2 * 128 * B} ids "
+          f"checked exactly (margin > 0.25), {s1.flips + s2.flips} near-tie flips")
 
 
 @pytest.mark.parametrize("act8", [False, True])

@@ -1,4 +1,4 @@
-"""Persistent decode GEMM (umv_gemm_decode, unimedvl_amd/csrc/gemm_decode.hip) through the C ABI.
+"""Persistent decode GEMM (umv_gemm_decode, EXPERIMENTAL, experimental/csrc/gemm_decode.hip) through the C ABI.
 The decode image only re-tiles the weight; the K split and summation order are those of the one-tile-per-workgroup
 kernels, so the results must be BIT-IDENTICAL to umv_gemm_bf16 / umv_gemm_fp8w on the same weight (which are themselves
 parity-tested against the fp32 / oracle references in test_kernels_gpu.py and test_fp8_gpu.py).  The fused RMSNorm
@@ -9,6 +9,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
+
+
+def _xops():
+    """the experimental package (experimental/): skip when its library has not been built (python -m experimental.build)"""
+    from experimental import _lib as xlib
+    if not xlib.available():
+        pytest.skip("experimental library not built (python -m experimental.build)")
+    from experimental import ops as xops
+    return xops
 
 
 def _ops():
@@ -44,14 +53,14 @@ def test_gemm_decode_bit_exact(N, K, swiglu, M, fp8):
         pytest.skip("umv_gemm_fp8w and the decode image agree bit for bit only when the 8 K slices coincide (K % 512 == 0)")
     g = torch.Generator().manual_seed(N + K + M)
     lin = _mk(ops, N, K, swiglu, fp8, g)
-    dl = ops.DecodeLinear(lin)
+    dl = _xops().DecodeLinear(lin)
     L = dl.layout
     rows = N // 2 if swiglu else N
     assert L.G * L.C >= rows and L.tpw * L.th >= L.C and L.th <= 16
     x = torch.randn(M, K, generator=g).to(BF16).cuda()
     res = None if swiglu else torch.randn(M, N, generator=g).to(BF16).cuda()
     ref = ops.gemm(x, lin, residual=res)
-    got = ops.gemm_decode(x, dl, residual=res)
+    got = _xops().gemm_decode(x, dl, residual=res)
     assert torch.equal(got, ref)
 
 
@@ -59,10 +68,12 @@ def test_gemm_decode_layouts_for_model_shapes():
     ops = _ops()
     from unimedvl_amd import _lib
     import ctypes as C
-    lib = _lib.load_experimental()
+    _xops()
+    from experimental import _lib as xlib
+    lib = xlib.load()
     want = {4608: (18, 9, 2), 3584: (14, 14, 1), 18944: (74, 15, 5), 152064: (594, None, None)}
     for rows, (c, th, tpw) in want.items():
-        L = _lib.DecodeLayout()
+        L = xlib.DecodeLayout()
         assert lib.umv_decode_layout_for(rows, 256, C.byref(L)) == 0
         assert L.G == 256 and L.C == c
         if th is not None:
@@ -76,12 +87,12 @@ def test_gemm_decode_fused_rmsnorm(N, K, swiglu, M):
     ops = _ops()
     g = torch.Generator().manual_seed(N + K + M + 1)
     lin = _mk(ops, N, K, swiglu, False, g, bias=not swiglu and N < 100000)
-    dl = ops.DecodeLinear(lin)
+    dl = _xops().DecodeLinear(lin)
     x = (torch.randn(M, K, generator=g) * 3).to(BF16).cuda()
     nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF16).cuda()
     xn = ops.rmsnorm(x, nw, 1e-6)
-    ref = ops.gemm_decode(xn, dl)
-    got = ops.gemm_decode(x, dl, norm_w=nw, norm_eps=1e-6)
+    ref = _xops().gemm_decode(xn, dl)
+    got = _xops().gemm_decode(x, dl, norm_w=nw, norm_eps=1e-6)
     # 1 ulp flips of single normalised activations perturb an output by <= 2^-8 * |x_k w_nk|; bound it loosely by the scale
     scale = ref.float().abs().max().clamp_min(1e-3)
     err = (got.float() - ref.float()).abs().max()
@@ -95,16 +106,16 @@ def test_gemm_decode_row_idx_and_errors():
     from unimedvl_amd import _lib
     g = torch.Generator().manual_seed(5)
     lin = _mk(ops, 512, 1024, False, False, g)
-    dl = ops.DecodeLinear(lin)
+    dl = _xops().DecodeLinear(lin)
     x = torch.randn(12, 1024, generator=g).to(BF16).cuda()
     idx = torch.tensor([7, 2, 9, 0, 11], dtype=torch.int32).cuda()
     o1 = torch.zeros(12, 512, dtype=BF16, device="cuda")
     o2 = torch.zeros(12, 512, dtype=BF16, device="cuda")
     ops.gemm(x, lin, out=o1, M=5, row_idx=idx)
-    ops.gemm_decode(x, dl, out=o2, M=5, row_idx=idx)
+    _xops().gemm_decode(x, dl, out=o2, M=5, row_idx=idx)
     assert torch.equal(o1, o2)
     with pytest.raises(_lib.UmvError, match="M <= 16"):
-        ops.gemm_decode(torch.randn(17, 1024).to(BF16).cuda(), dl)
-    big = ops.DecodeLinear(_mk(ops, 64, 8192, False, False, g))
+        _xops().gemm_decode(torch.randn(17, 1024).to(BF16).cuda(), dl)
+    big = _xops().DecodeLinear(_mk(ops, 64, 8192, False, False, g))
     with pytest.raises(_lib.UmvError, match="K <= 4096"):
-        ops.gemm_decode(torch.randn(4, 8192).to(BF16).cuda(), big, norm_w=torch.ones(8192, dtype=BF16, device="cuda"))
+        _xops().gemm_decode(torch.randn(4, 8192).to(BF16).cuda(), big, norm_w=torch.ones(8192, dtype=BF16, device="cuda"))

@@ -137,10 +137,9 @@ def test_decode_session_splitk_matches_default(tiny_weights, monkeypatch):
             return prompts[int(s)]
 
     runs = {}
-    modes = ("0", "2,2,3", "3,1,2", "nofuse:2,1,3")   # every GEMM split or not, partial sums into the fused attention or qkv_post
+    modes = ("0", "2,2,3", "3,1,2", "2,1,3")   # every GEMM split or not (the QKV partial sums go into umv_qkv_post)
     for mode in modes:
-        monkeypatch.setenv("UMV_DECODE_FUSE_ATTN", "0" if mode.startswith("nofuse:") else "1")
-        monkeypatch.setenv("UMV_DECODE_SPLITK", mode.split(":")[-1])
+        monkeypatch.setenv("UMV_DECODE_SPLITK", mode)
         cache = NaiveCache(cfg["layers"])
         gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], Tok(), NEW_TOKEN_IDS)
         cache = model.forward_cache_update_text(cache, **gi)
@@ -149,8 +148,7 @@ def test_decode_session_splitk_matches_default(tiny_weights, monkeypatch):
             from copy import deepcopy
             sess = DecodeSession(model.language_model, deepcopy(cache), gi["packed_start_tokens"], gi["packed_query_position_ids"], 6,
                                  use_graph=use_graph)
-            assert sess.sk == ((1, 1, 1) if mode == "0" else tuple(int(v) for v in mode.split(":")[-1].split(",")))
-            assert sess.fuse_attn == (not mode.startswith("nofuse:"))
+            assert sess.sk == ((1, 1, 1) if mode == "0" else tuple(int(v) for v in mode.split(",")))
             logits = []
             for _ in range(5):
                 sess.step(1)

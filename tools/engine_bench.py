@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Decode layer engine (unimedvl_amd/engine.py, csrc/decode_engine.hip) against the kernel chain it replaces:
+"""Decode layer engine (experimental/engine.py, experimental/csrc/decode_engine.hip) against the kernel chain it replaces:
 bit-level comparison of every intermediate of one decoder layer after its attention, then timing of N_LAYERS
 distinct layers' worth of weights back to back (nothing cache resident) under a HIP graph.
 
@@ -12,7 +12,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from unimedvl_amd import engine, ops  # noqa: E402
+from unimedvl_amd import ops  # noqa: E402
+from experimental import engine  # noqa: E402
 
 H, I, QKV = 3584, 18944, 4608
 BF16 = torch.bfloat16

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from unimedvl_amd import ops  # noqa: E402
+from experimental import ops as xops  # noqa: E402  (DEC=1: the experimental persistent decode GEMM)
 
 H, I, QKV, V = 3584, 18944, 4608, 152064
 BF16 = torch.bfloat16
@@ -47,14 +48,14 @@ def main():
                 if exact:
                     lin = lin.for_decode()
             if dec:
-                lin = ops.DecodeLinear(lin)
+                lin = xops.DecodeLinear(lin)
             elif fp8:
                 lin.wp = None   # only the e4m3 image is streamed at M <= 64
             lins.append(lin)
         x = torch.randn(B, K, device="cuda").to(BF16)
         out = torch.empty(B, N // 2 if swiglu else N, device="cuda", dtype=BF16)
         nw = torch.ones(K, device="cuda", dtype=BF16) if (norm and K <= 4096) else None
-        mm = ops.gemm_decode if dec else ops.gemm
+        mm = xops.gemm_decode if dec else ops.gemm
         split = int(os.environ.get("SPLIT", "0"))   # split-K mode (fp32 partials, finished by the consumer kernel)
         if split > 1 and not swiglu:
             part = torch.empty(split, B, N, device="cuda", dtype=torch.float32)

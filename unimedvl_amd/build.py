@@ -15,12 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libunimedvl_hip.so")
-LIB_EXPERIMENTAL = os.path.join(LIBDIR, "libunimedvl_hip_experimental.so")
-# the product library (include/unimedvl_hip.h) ...
+# the product library (include/unimedvl_hip.h): everything the entry points call.  The kernels that were measured and not adopted
+# live in experimental/ with a build target of their own (python -m experimental.build).
 SOURCES = ["host_error.hip", "elementwise.hip", "gemm.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "vision.hip"]
-# ... and the experimental one (include/unimedvl_hip_experimental.h): measured, not adopted, kept with its tests; nothing on the
-# product path loads it
-SOURCES_EXPERIMENTAL = ["host_error.hip", "gemm_decode.hip", "attention_decode.hip", "attention_prefill32.hip", "decode_engine.hip", "prefetch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 # per-file additions.  attention_prefill: MFMA destinations stay in VGPRs (the compiler's default parks the 64 O accumulators in
@@ -30,7 +27,7 @@ FILE_FLAGS = {"attention_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 def _stamp():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["../../include/unimedvl_hip.h", "../../include/unimedvl_hip_experimental.h"]:
+    for f in sorted(os.listdir(CSRC)) + ["../../include/unimedvl_hip.h"]:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(open(p, "rb").read())
@@ -43,12 +40,12 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     stamp_file = os.path.join(LIBDIR, "build.stamp")
     stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(LIB_EXPERIMENTAL) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     procs = []
     groups = []
-    for lib, sources, extra, suffix in ((LIB, SOURCES, [], ""), (LIB_EXPERIMENTAL, SOURCES_EXPERIMENTAL, ["-DUMV_EXPERIMENTAL_LIB"], ".exp")):
+    for lib, sources, extra, suffix in ((LIB, SOURCES, [], ""),):
         objs = []
         for src in sources:
             sp = os.path.join(CSRC, src)

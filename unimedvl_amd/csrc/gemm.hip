@@ -706,6 +706,15 @@ constexpr int interleave_slot(int i, int nmma, int nrd) {
 __device__ __forceinline__ void mfma16_asm(f32x4& c, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// the same with the accumulator in the AGPR half of the register file (4-wave tiles with 128 x 128 per wave: 256 accumulator
+// registers, one wave per SIMD on the full 512-entry file)
+__device__ __forceinline__ void mfma16_asm_acc(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // one 32x32 MFMA C/D fragment
+__device__ __forceinline__ void mfma32_asm(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 
 // WN x WM waves, each owning TN x TM MFMA tiles: workgroup tile (WN*TN*16)(n) x (WM*TM*16)(m) x (KTS*32)(k),
 // NBUF LDS buffers.  Pipeline per k-step t (one raw s_barrier, never a full vmcnt drain in steady state):
@@ -798,6 +807,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             const int mm = m < a.M ? m : a.M - 1;
             const int64_t row = a.row_idx ? (int64_t)a.row_idx[mm] : (int64_t)mm;
             src[i] = a.x + row * a.ldx + (kt0 + kk) * 32 + g * 8;
+            if constexpr ((SCHED >> 4) == 6) src[i] = a.x + (int64_t)m0 * a.ldx + fx * 512 + lane * 8;   // ablation 6: x read as contiguous KiB (wrong data)
         }
     }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     for (int i = 0; i < TPW; ++i) {
         const int f = wave * TPW + i;
         cur[i] = tvalid[i] ? src[i] : zero;
-        bump[i] = !tvalid[i] ? 0 : (f < WTILES ? KTS * 512 : KTS * 32);
+        bump[i] = !tvalid[i] ? 0 : (f < WTILES ? KTS * 512 : ((SCHED >> 4) == 6 ? XTILES * 512 : KTS * 32));
     }
     const bool ragged = (KTL % KTS) != 0 || ((a.K & 31) != 0 && kt1 == KT);     // the last k-step needs per-tile / per-lane zero fill
     auto stage = [&](int step, int buf) {
@@ -848,26 +858,50 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    constexpr bool PX = (SCHED & 15) == 3;     // paired x staging: see the SCH == 3 block below
 #pragma unroll
-    for (int p = 0; p < NBUF - 1; ++p) {
+    for (int p = 0; p < (PX ? 0 : NBUF - 1); ++p) {
         if (p < nsteps) stage(p, p);
-        else if (SCHED == 1) {       // (K < 96) keep the number of pieces in flight uniform: see the interleaved loop below
+        else if (SCHED != 0) {       // (K < 96) keep the number of pieces in flight uniform: see the interleaved loop below
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
                 __builtin_amdgcn_global_load_lds((const void*)zero, (lds_ptr_t)dst_of(p, wave * TPW + i), 16, 0, 0);
         }
     }
-    if constexpr (SCHED == 1) {
+    // SCHED = 2: the interleaved schedule on v_mfma_f32_32x32x16_bf16.  Same LDS image (1 KiB tiles in 16x16x32 fragment order), same
+    // number of fragment reads per k-step; a 32 x 32 x 16 operand is gathered from TWO neighbouring 16-row tiles by giving the
+    // lanes the addresses  tile[(lane >> 4) & 1] + ((2h + (lane >> 5)) * 16 + (lane & 15)) * 16  (h = k half of the step) - the
+    // four quarter-wave groups of a ds_read_b128 still cover 256 distinct bytes mod 256 each: conflict free.  Half the matrix
+    // instructions per k-step (16 of 8 passes each instead of 32 of 4 for the 256 x 256 tile), the accumulators stay 128 registers.
+    // SCHED >> 4 = ablation number (TIMING ONLY, results are wrong; UMV_GEMM_TILE=966x, tools/r04_gemm_sweep.sh): 1 no LDS-DMA pieces
+    // in the main loop, 2 every other fragment read, 3 no MFMAs, 4 no barrier, 5 MFMAs + barrier only, 6 x pieces read contiguous
+    // KiB instead of 16 rows x 64 B, 7 no x pieces, 8 no W pieces
+    constexpr int ABL = SCHED >> 4, SCH = SCHED & 15;
+    constexpr bool M32 = SCH == 2;
+    static_assert(!M32 || (TN % 2 == 0 && TM % 2 == 0), "32x32 MFMA tiles need even TN / TM");
+    f32x16 acc32[M32 ? TN / 2 : 1][M32 ? TM / 2 : 1];
+    if constexpr (M32) {
+#pragma unroll
+        for (int u = 0; u < TN / 2; ++u)
+#pragma unroll
+            for (int v = 0; v < TM / 2; ++v)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc32[u][v][q] = 0.f;
+    }
+    if constexpr (SCH == 1 || SCH == 2) {
         // Interleaved schedule (KTS == 1).  With the plain loop every wave leaves the barrier, issues its 12 ds_read_b128
         // at once and only then its 32 MFMAs: the 8 waves' 96 KiB of fragment reads keep the LDS pipe busy for ~768
         // cycles during which the matrix pipes mostly wait, then LDS idles for the ~1024 cycles of MFMAs - the two phases
         // add up (MfmaUtil 44 % from the PMC counters).  Here the fragments of tile t+1 are requested one ds_read at a
         // time, spread evenly between the MFMAs of tile t (every 2-3 MFMAs for the 256 x 256 tile), so each wave starts its MFMAs right after the barrier and the LDS traffic is spread
         // over the whole step.  MFMAs and ds_reads are inline asm so that the order is exactly the one written.
-        static_assert(SCHED != 1 || (KTS == 1 && NBUF >= 3), "interleaved schedule needs KTS == 1 and >= 3 LDS buffers");
+        static_assert(SCHED == 0 || (KTS == 1 && NBUF >= 3), "interleaved schedule needs KTS == 1 and >= 3 LDS buffers");
         bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
         const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-        const uint32_t woff = wn * TN * 1024 + lane * 16, xoff = WTILES * 1024 + wm * TM * 1024 + lane * 16;
+        // fragment i of a wave's W (x) tiles: 16x16x32 = tile i, lane-linear; 32x32x16 = tile pair i >> 1, k half i & 1
+        const uint32_t lane_off = M32 ? (uint32_t)(((lane >> 4) & 1) * 1024 + ((lane >> 5) * 16 + (lane & 15)) * 16) : (uint32_t)(lane * 16);
+        const uint32_t woff = wn * TN * 1024 + lane_off, xoff = WTILES * 1024 + wm * TM * 1024 + lane_off;
+        constexpr auto frag_off = [](int i) constexpr { return M32 ? (i >> 1) * 2048 + (i & 1) * 512 : i * 1024; };
         auto wait_tiles = [&](int allowed) {   // tiles (of TPW DMA ops each) that may stay in flight
             if (allowed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
             else if (allowed == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
@@ -884,15 +918,15 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         UMV_BARRIER();
         static_for<0, TN>([&](auto T) {
             constexpr int t = decltype(T)::value;
-            lds_read_frag<t * 1024>(wfA[t], lds0 + woff);
+            lds_read_frag<frag_off(t)>(wfA[t], lds0 + woff);
         });
         static_for<0, TM>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            lds_read_frag<j * 1024>(xfA[j], lds0 + xoff);
+            lds_read_frag<frag_off(j)>(xfA[j], lds0 + xoff);
         });
         land(wfA, xfA);
-        constexpr int NRD = TN + TM, NMMA = TN * TM;
-        static_assert(SCHED != 1 || NRD <= NMMA, "at most one fragment read per MFMA");
+        constexpr int NRD = TN + TM, NMMA = M32 ? TN * TM / 2 : TN * TM;
+        static_assert(SCHED == 0 || NRD <= NMMA, "at most one fragment read per MFMA");
         // The TPW LDS-DMA pieces of tile step + NBUF - 1 are issued BETWEEN the MFMAs as well, one every NMMA / TPW MFMAs.
         // Issued in a burst behind the barrier (as the fragment reads once were) they keep the wave off the matrix pipe for
         // TPW x 100-185 cycles per k-step (the guide's price of a piece inside a busy phase) while its twin on the SIMD, in
@@ -901,10 +935,10 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         // sequence for every step: the ragged last tile swaps its source pointers in before the sequence, and the last
         // NBUF - 1 steps, which have nothing left to stage, copy the zero page into the (free) buffer so that the count of
         // pieces in flight stays the same at every wait.
-        static_assert(SCHED != 1 || TPW <= NMMA, "at most one DMA piece per MFMA");
+        static_assert(SCHED == 0 || TPW <= NMMA, "at most one DMA piece per MFMA");
         auto body = [&](int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
             wait_tiles(NBUF - 3);                                        // tile step+1 landed (mine); tile step+2's pieces may fly
-            UMV_BARRIER();                                // ... everyone's; and tile step-1's buffer is free
+            if constexpr (ABL != 4) UMV_BARRIER();        // ... everyone's; and tile step-1's buffer is free
             const int st = step + NBUF - 1;                              // the tile staged during this step
             if (st >= nsteps) {
 #pragma unroll
@@ -931,14 +965,24 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             const uint32_t nb = lds0 + ((step + 1) % NBUF) * BUF;
             const uint32_t wa = nb + woff, xa = nb + xoff;
             static_for<0, NMMA>([&](auto I) {
-                constexpr int i = decltype(I)::value, t = i / TM, j = i % TM;
-                mfma16_asm(acc[t][j], wc[t], xc[j]);
-                constexpr int rd = interleave_slot(i, NMMA, NRD);   // the read (if any) that follows MFMA i
-                if constexpr (rd >= 0 && rd < TN) lds_read_frag<(rd < TN ? rd : 0) * 1024>(wnx[rd < TN ? rd : 0], wa);
-                else if constexpr (rd >= TN) lds_read_frag<(rd >= TN ? rd - TN : 0) * 1024>(xnx[rd >= TN ? rd - TN : 0], xa);
+                constexpr int i = decltype(I)::value;
+                if constexpr (ABL == 3) {
+                } else if constexpr (M32) {      // k half outermost: two MFMAs on one accumulator are NMMA / 2 instructions apart
+                    constexpr int h = i / (NMMA / 2), rem = i % (NMMA / 2), u = rem / (TM / 2), v = rem % (TM / 2);
+                    mfma32_asm(acc32[u][v], wc[2 * u + h], xc[2 * v + h]);
+                } else {
+                    constexpr int t = i / TM, j = i % TM;
+                    if constexpr (TN * TM > 40) mfma16_asm_acc(acc[t][j], wc[t], xc[j]);     // more accumulators than VGPRs can hold beside the fragments
+                    else mfma16_asm(acc[t][j], wc[t], xc[j]);
+                }
+                constexpr int rd0 = interleave_slot(i, NMMA, NRD);   // the read (if any) that follows MFMA i
+                constexpr int rd = (ABL == 5 || (ABL == 2 && (rd0 & 1))) ? -1 : rd0;
+                if constexpr (rd >= 0 && rd < TN) lds_read_frag<frag_off(rd < TN ? rd : 0)>(wnx[rd < TN ? rd : 0], wa);
+                else if constexpr (rd >= TN) lds_read_frag<frag_off(rd >= TN ? rd - TN : 0)>(xnx[rd >= TN ? rd - TN : 0], xa);
                 constexpr int pc = dma_slot(i, NMMA, TPW);          // the DMA piece (if any) that follows MFMA i
-                if constexpr (pc >= 0) {
+                if constexpr (pc >= 0 && ABL != 1 && ABL != 5) {
                     __builtin_amdgcn_sched_barrier(0);
+                    if (!(ABL == 7 && wave * TPW + pc >= WTILES) && !(ABL == 8 && wave * TPW + pc < WTILES))
                     __builtin_amdgcn_global_load_lds((const void*)cur[pc], (lds_ptr_t)dst_of(dma_buf, wave * TPW + pc), 16, 0, 0);
                     cur[pc] += bump[pc];
                     __builtin_amdgcn_sched_barrier(0);
@@ -952,6 +996,168 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing zero-page pieces: the epilogue reuses the buffers
         // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> VALU-read wait states by hand
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if constexpr (M32) {
+            // rename the 32 x 32 accumulators into the quads the epilogue takes (gemm_epilogue.h, L32): quad q of tile (u, v) is
+            // rows q * 8 + 4 * (lane >> 5) .. + 3 of the tile's n side = column tile 2u + (q >> 1), column group 2 (q & 1) + (lane >> 5)
+            static_for<0, TN / 2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                static_for<0, TM / 2>([&](auto V) {
+                    constexpr int v = decltype(V)::value;
+                    asm volatile("" : "+v"(acc32[u][v]));
+                    static_for<0, 4>([&](auto Q) {
+                        constexpr int q = decltype(Q)::value;
+                        acc[2 * u + (q >> 1)][2 * v + (q & 1)] =
+                            (f32x4){acc32[u][v][4 * q], acc32[u][v][4 * q + 1], acc32[u][v][4 * q + 2], acc32[u][v][4 * q + 3]};
+                    });
+                });
+            });
+        } else if constexpr (TN * TM > 40) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[t][j]));
+        } else {
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[t][j]));
+        }
+    } else if constexpr (PX) {
+        // SCHED = 3: the interleaved schedule of SCHED = 1 with the x pieces staged in PAIRS of k-steps.  An x piece gathers 16 rows
+        // x 64 bytes - HALF of a 128-byte line per row; the other half is the piece of the next k-step, a whole step (~0.8 us) later,
+        // when the line has long left the 32 KiB L1: every x line travels L2 -> L1 twice and holds a miss entry twice as long per
+        // byte as a W line (measured, 8192^3: x pieces read as contiguous KiB instead - wrong data, timing only - 827 -> 766 us; no
+        // x pieces at all 712; no W pieces 663; no pieces 535).  Here a wave issues the pieces of k-tiles t+3 and t+4 (an even /
+        // odd pair = the two halves of the same lines) of one 16-row tile back to back in the ODD step t - the second request meets
+        // the line in flight or in L1 - and none in even steps; W tiles are staged three steps ahead as before.  Same LDS image,
+        // same fragment reads, same MFMA order: results are bit-identical to SCHED = 1.  Every wave stages WPW W tiles per step and
+        // XPW x row-tiles per pair.  The body of step t computes on tile t (in registers) and reads the fragments of tile t + 1, so
+        // its head waits for tile t + 1:  even t -> W(t+1) came in body t-2 and behind it went x(t+2), x(t+3), W(t+2) of body t-1:
+        // 2 XPW + WPW pieces may still fly;  odd t -> x(t+1), W(t+1) came in body t-2 and only W(t+2) of body t-1 is behind them.
+        // Buffers: x(t+4) takes the buffer of tile t, free once every wave has passed the head barrier of body t.
+        constexpr int WPW = WTILES / NW, XPW = XTILES / NW;
+        static_assert(KTS == 1 && NBUF == 4 && WTILES % NW == 0 && XTILES % NW == 0 && NDUMMY == 0, "paired x staging: 4 buffers, even split of the tiles over the waves");
+        constexpr int NRD = TN + TM, NMMA = TN * TM;
+        static_assert(NRD <= NMMA && 2 * XPW + WPW <= NMMA, "at most one read / piece per MFMA");
+        const bool ragged_k = (a.K & 31) != 0 && kt1 == KT;      // the last k-tile needs per-lane zero fill
+        // W: tile wave * WPW + i of the block; x: row-tile wave * XPW + i, two k-tiles (even, odd) per pair
+        const bf16_t* curW[WPW];
+        int bumpW[WPW];
+        const bf16_t* curX[XPW][2];
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int nt = nt_blk + wave * WPW + i;
+            const bool ok = nt < NTT;
+            curW[i] = ok ? a.wp + ((int64_t)nt * KT + kt0) * 512 + lane * 8 : zero;
+            bumpW[i] = ok ? 512 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int m = m0 + (wave * XPW + i) * 16 + r;
+            const int mm = m < a.M ? m : a.M - 1;                // rows past M are clamped (their outputs are masked)
+            const int64_t row = a.row_idx ? (int64_t)a.row_idx[mm] : (int64_t)mm;
+            curX[i][0] = a.x + row * a.ldx + kt0 * 32 + g * 8;
+            curX[i][1] = curX[i][0] + 32;
+        }
+        // (char* and a cast at the call: a lambda RETURNING an address_space(3) pointer makes the host pass drop the kernel's stub
+        // without a diagnostic - the library then fails to load with an undefined __device_stub__ symbol)
+        auto dstW = [&](int buf, int i) -> char* { return smem + buf * BUF + (wave * WPW + i) * 1024; };
+        auto dstX = [&](int buf, int i) -> char* { return smem + buf * BUF + (WTILES + wave * XPW + i) * 1024; };
+        // the W pieces of k-tile kt (relative to kt0) / the x pieces of k-tiles kt, kt + 1: pointers for this issue, then the bump.
+        // Tiles past the K range read the zero page (and keep the count of pieces in flight uniform); the last, partial k-tile
+        // selects per lane.
+        const bf16_t* pw[WPW];
+        const bf16_t* px[XPW][2];
+        auto prep_w = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) {
+                pw[i] = kt < KTL ? curW[i] : zero;
+                curW[i] += bumpW[i];
+            }
+        };
+        auto prep_x = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < XPW; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16_t* p = curX[i][h];
+                    if (kt + h >= KTL) p = zero;
+                    else if (ragged_k && kt + h == KTL - 1) p = ((kt0 + kt + h) * 32 + g * 8 < a.K) ? p : zero;
+                    px[i][h] = p;
+                    curX[i][h] += 64;
+                }
+        };
+        // prologue, in the order the loop would have issued them: W(0), x(0), x(1), W(1), x(2), x(3), W(2)
+#pragma unroll
+        for (int t = 0; t <= 2; ++t) {
+            if (t != 1) {
+                prep_x(t);
+#pragma unroll
+                for (int i = 0; i < XPW; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) __builtin_amdgcn_global_load_lds((const void*)px[i][h], (lds_ptr_t)dstX(t + h, i), 16, 0, 0);
+            }
+            prep_w(t);
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) __builtin_amdgcn_global_load_lds((const void*)pw[i], (lds_ptr_t)dstW(t, i), 16, 0, 0);
+        }
+        bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+        const uint32_t woff = wn * TN * 1024 + lane * 16, xoff = WTILES * 1024 + wm * TM * 1024 + lane * 16;
+        auto land = [&](bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(wf[t]));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
+        };
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPW + 2 * XPW) : "memory");      // x(0), x(1), W(0) landed
+        UMV_BARRIER();
+        static_for<0, TN>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            lds_read_frag<t * 1024>(wfA[t], lds0 + woff);
+        });
+        static_for<0, TM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            lds_read_frag<j * 1024>(xfA[j], lds0 + xoff);
+        });
+        land(wfA, xfA);
+        auto body = [&](auto EVEN, int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
+            constexpr bool even = decltype(EVEN)::value;
+            constexpr int NP = even ? WPW : 2 * XPW + WPW;
+            // the fragments of tile `step` are in registers; tile step + 1 must have landed before its reads below
+            if constexpr (even) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XPW + WPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+            UMV_BARRIER();                                   // ... everyone's; and the buffers of tiles step - 1 and step are free
+            if constexpr (!even) prep_x(step + 3);
+            prep_w(step + 3);
+            const int bw = (step + 3) % NBUF, bx0 = (step + 3) % NBUF;
+            const uint32_t nb = lds0 + ((step + 1) % NBUF) * BUF;
+            const uint32_t wa = nb + woff, xa = nb + xoff;
+            static_for<0, NMMA>([&](auto I) {
+                constexpr int i = decltype(I)::value, t = i / TM, j = i % TM;
+                mfma16_asm(acc[t][j], wc[t], xc[j]);
+                constexpr int rd = interleave_slot(i, NMMA, NRD);
+                if constexpr (rd >= 0 && rd < TN) lds_read_frag<(rd < TN ? rd : 0) * 1024>(wnx[rd < TN ? rd : 0], wa);
+                else if constexpr (rd >= TN) lds_read_frag<(rd >= TN ? rd - TN : 0) * 1024>(xnx[rd >= TN ? rd - TN : 0], xa);
+                constexpr int pc = dma_slot(i, NMMA, NP);
+                if constexpr (pc >= 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!even && pc < 2 * XPW)
+                        __builtin_amdgcn_global_load_lds((const void*)px[pc / 2][pc % 2], (lds_ptr_t)dstX((bx0 + pc % 2) % NBUF, pc / 2), 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((const void*)pw[even ? pc : pc - 2 * XPW], (lds_ptr_t)dstW(bw, even ? pc : pc - 2 * XPW), 16, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            land(wnx, xnx);
+        };
+        for (int step = 0; step < nsteps; step += 2) {
+            body(std::true_type{}, step, wfA, xfA, wfB, xfB);
+            if (step + 1 < nsteps) body(std::false_type{}, step + 1, wfB, xfB, wfA, xfA);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
         for (int t = 0; t < TN; ++t)
@@ -993,22 +1199,22 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     constexpr bool LDS_EPI = BN * BM * 2 <= NBUF * BUF;
     if (LDS_EPI && !(e.flags & UMV_EPI_OUT_F32) && lds_epilogue_enabled) {
         UMV_BARRIER();      // every wave has read its last fragments: the staging buffers are free
-        epi_wave_tile_lds<TN, TM>(e, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, a.M, a.row_idx, nt_base, NTT,
-                                  bias_lds + wn * TN * 16);
+        epi_wave_tile_lds<TN, TM, M32>(e, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, a.M, a.row_idx, nt_base, NTT,
+                                       bias_lds + wn * TN * 16);
         return;
     }
     const bool swiglu = (a.epilogue & UMV_EPI_SWIGLU) != 0;
     if (swiglu) {
         static_for<0, TM>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            const int m = m0 + (wm * TM + j) * 16 + r;
+            const int m = m0 + wm * TM * 16 + epi_row_of<M32>(j, lane);
             if (m < a.M) {
                 const int64_t orow = a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m;
                 static_for<0, TN / 2>([&](auto P) {
                     constexpr int p = decltype(P)::value;
                     const int ntile = nt_base + 2 * p;
                     if (ntile < NTT) {
-                        const int c0 = (ntile >> 1) * 16 + g * 4;
+                        const int c0 = (ntile >> 1) * 16 + epi_grp_of<M32>(j, lane) * 4;
                         float gg[4] = {acc[2 * p][j].x, acc[2 * p][j].y, acc[2 * p][j].z, acc[2 * p][j].w};
                         float uu[4] = {acc[2 * p + 1][j].x, acc[2 * p + 1][j].y, acc[2 * p + 1][j].z, acc[2 * p + 1][j].w};
                         epi_swiglu4(e, orow, c0, a.N / 2, gg, uu);
@@ -1023,21 +1229,25 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     bool mok[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + (wm * TM + j) * 16 + r;
+        const int m = m0 + wm * TM * 16 + epi_row_of<M32>(j, lane);
         mok[j] = m < a.M;
         orow[j] = (mok[j] && a.row_idx) ? (int64_t)a.row_idx[m] : (int64_t)m;
     }
     static_for<0, TN>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        const int n0 = (nt_base + t) * 16 + g * 4;
-        if (n0 < a.N) {
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (e.flags & UMV_EPI_BIAS) epi_bias4(e, n0, b4);
-            static_for<0, TM>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                if (mok[j]) epi_store4(e, orow[j], n0, acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w, nullptr, b4);
-            });
-        }
+        static_for<0, (M32 ? 2 : 1)>([&](auto GI) {       // the one or two column groups this lane meets in column tile t
+            constexpr int gi = decltype(GI)::value;
+            const int n0 = (nt_base + t) * 16 + epi_grp_of<M32>(gi, lane) * 4;
+            if (n0 < a.N) {
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (e.flags & UMV_EPI_BIAS) epi_bias4(e, n0, b4);
+                static_for<0, TM>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    if constexpr (!M32 || (j & 1) == gi)
+                        if (mok[j]) epi_store4(e, orow[j], n0, acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w, nullptr, b4);
+                });
+            }
+        });
     });
 }
 
@@ -1219,6 +1429,22 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
     if (cfg == 288) return launch_tiled<2, 4, 9, 2, 1, 4, 1>(a, KT, NTT, s);   // 288(n)x128(m)x32: N = 1152 / 4608 = 4 / 16 x 288 -> 256 tiles at 8192 / 2048 rows
     if (cfg == 266) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, MFMA / ds_read interleaved by hand
+    if (cfg == 9661) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 1>(a, KT, NTT, s);   // ablations of 266 (timing only)
+    if (cfg == 9662) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 2>(a, KT, NTT, s);
+    if (cfg == 9663) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 3>(a, KT, NTT, s);
+    if (cfg == 9664) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 4>(a, KT, NTT, s);
+    if (cfg == 9665) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 5>(a, KT, NTT, s);
+    if (cfg == 9666) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 6>(a, KT, NTT, s);
+    if (cfg == 9667) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 7>(a, KT, NTT, s);
+    if (cfg == 9668) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 8>(a, KT, NTT, s);
+    if (cfg == 366) return launch_tiled<2, 4, 8, 4, 1, 4, 3>(a, KT, NTT, s);   // 266 / 268 / 384 / 270 with the x pieces staged in pairs of k-steps (SCHED = 3)
+    if (cfg == 368) return launch_tiled<4, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
+    if (cfg == 484) return launch_tiled<4, 2, 6, 4, 1, 4, 3>(a, KT, NTT, s);
+    if (cfg == 370) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
+    if (cfg == 566) return launch_tiled<2, 4, 8, 4, 1, 4, 2>(a, KT, NTT, s);   // the same tiles on v_mfma_f32_32x32x16_bf16 (SCHED = 2)
+    if (cfg == 568) return launch_tiled<4, 2, 4, 4, 1, 4, 2>(a, KT, NTT, s);
+    if (cfg == 684) return launch_tiled<4, 2, 6, 4, 1, 4, 2>(a, KT, NTT, s);
+    if (cfg == 570) return launch_tiled<2, 2, 4, 4, 1, 4, 2>(a, KT, NTT, s);
     if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
     if (cfg == 384) return launch_tiled<4, 2, 6, 4, 1, 4, 1>(a, KT, NTT, s);   // 384(n)x128(m)x32, 8 waves of 96 x 64: N = 1152 = 3 x 384 without padding
     if (cfg == 270) return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 128x128x32, 4 waves, 4 buffers (64 KiB, 2 WG/CU), interleaved

@@ -190,17 +190,25 @@ __device__ __forceinline__ int epi_swz(int chunk, int row) {
     else return (chunk + row) % CH;
 }
 
-template <int TN, int TM>
+// L32: the accumulators come from 32x32x16 MFMAs, renamed by the caller into f32x4 quads acc[t][j] that hold, for this lane, row
+// (j >> 1) * 32 + (lane & 31) and columns t * 16 + (2 * (j & 1) + (lane >> 5)) * 4 .. + 3 of the wave tile (quad q of the 32 x 32
+// tile (u, v) is acc[2u + (q >> 1)][2v + (q & 1)]); otherwise the 16x16x32 layout: row j * 16 + (lane & 15), columns
+// t * 16 + (lane >> 4) * 4 .. + 3.  Only the lane -> (row, column group) map differs; arithmetic and roundings are the same.
+template <bool L32>
+__device__ __forceinline__ int epi_row_of(int j, int lane) { return L32 ? (j >> 1) * 32 + (lane & 31) : j * 16 + (lane & 15); }
+template <bool L32>
+__device__ __forceinline__ int epi_grp_of(int j, int lane) { return L32 ? 2 * (j & 1) + (lane >> 5) : (lane >> 4); }
+
+template <int TN, int TM, bool L32 = false>
 __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[TN][TM], char* wreg, int lane, int m_wave0, int M,
                                                   const int32_t* __restrict__ row_idx, int nt_base, int NTT,
                                                   const bf16_t* bias_tile = nullptr,   // LDS copy of bias[nt_base*16 ..], zero past N
                                                   const float* __restrict__ sw = nullptr, const float* __restrict__ sx = nullptr) {
-    const int r = lane & 15, g = lane >> 4;
     const bool swiglu = (e.flags & UMV_EPI_SWIGLU) != 0;
     float sxr[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m_wave0 + j * 16 + r;
+        const int m = m_wave0 + epi_row_of<L32>(j, lane);
         sxr[j] = sx ? sx[m < M ? m : M - 1] : 1.f;
     }
     auto finish = [&](auto CHC, int col_base, int n_out) {
@@ -254,7 +262,7 @@ __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[
             constexpr int p = decltype(P)::value;
             static_for<0, TM>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const int row = j * 16 + r;
+                const int row = epi_row_of<L32>(j, lane), g = epi_grp_of<L32>(j, lane);
                 float v[4];
                 const float gg[4] = {acc[2 * p][j].x, acc[2 * p][j].y, acc[2 * p][j].z, acc[2 * p][j].w};
                 const float uu[4] = {acc[2 * p + 1][j].x, acc[2 * p + 1][j].y, acc[2 * p + 1][j].z, acc[2 * p + 1][j].w};
@@ -281,32 +289,42 @@ __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[
         constexpr int CH = 2 * TN;
         static_for<0, TN>([&](auto T) {
             constexpr int t = decltype(T)::value;
-            const int n0 = (nt_base + t) * 16 + g * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {1.f, 1.f, 1.f, 1.f};
-            if (e.flags & UMV_EPI_BIAS) {
-                if (bias_tile) {
-                    const u32x2 pk = *reinterpret_cast<const u32x2*>(bias_tile + t * 16 + g * 4);
-                    b4[0] = __uint_as_float(pk.x << 16); b4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
-                    b4[2] = __uint_as_float(pk.y << 16); b4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
-                } else if (n0 < e.N) {
-                    epi_bias4(e, n0, b4);
-                }
-            }
-            if (sw) {
+            // the column group of a quad depends on the lane alone (16x16x32) or on the lane and the parity of j (32x32x16):
+            // bias / scales of the one or two groups this lane meets in column tile t
+            constexpr int NG = L32 ? 2 : 1;
+            float b4[NG][4], s4[NG][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s4[q] = sw[min(n0 + q, e.N - 1)];
+            for (int gi = 0; gi < NG; ++gi) {
+                const int g = epi_grp_of<L32>(gi, lane);
+                const int n0 = (nt_base + t) * 16 + g * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { b4[gi][q] = 0.f; s4[gi][q] = 1.f; }
+                if (e.flags & UMV_EPI_BIAS) {
+                    if (bias_tile) {
+                        const u32x2 pk = *reinterpret_cast<const u32x2*>(bias_tile + t * 16 + g * 4);
+                        b4[gi][0] = __uint_as_float(pk.x << 16); b4[gi][1] = __uint_as_float(pk.x & 0xFFFF0000u);
+                        b4[gi][2] = __uint_as_float(pk.y << 16); b4[gi][3] = __uint_as_float(pk.y & 0xFFFF0000u);
+                    } else if (n0 < e.N) {
+                        epi_bias4(e, n0, b4[gi]);
+                    }
+                }
+                if (sw) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s4[gi][q] = sw[min(n0 + q, e.N - 1)];
+                }
             }
             static_for<0, TM>([&](auto J) {
                 constexpr int j = decltype(J)::value;
-                const int row = j * 16 + r;
+                constexpr int gi = L32 ? (j & 1) : 0;
+                const int row = epi_row_of<L32>(j, lane), g = epi_grp_of<L32>(j, lane);
                 float v[4] = {acc[t][j].x, acc[t][j].y, acc[t][j].z, acc[t][j].w};
                 if (sw) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] * s4[q] * sxr[j];
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] * s4[gi][q] * sxr[j];
                 }
                 if (e.flags & UMV_EPI_BIAS) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += b4[q];
+                    for (int q = 0; q < 4; ++q) v[q] += b4[gi][q];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = rbf(v[q]);

@@ -125,13 +125,9 @@ class DecodeSession:
                         for lw, slot in zip(w.und, w.decode_copies)]
         else:
             self.dec = [(lw.qkv, lw.o, lw.down) for lw in w.und]
-        # q/k norm + RoPE + KV append inside the attention kernel (umv_attn_decode_fused) saves a launch per layer, but every
-        # key-split wave then repeats the norm prologue (~3 us of VALU work on its critical path).  Measured (ms per step,
-        # fused vs umv_qkv_post + umv_attn_varlen): QKV not split, B=8: 3.32 vs 3.39 (fused wins); QKV split 3 ways - the
-        # prologue also sums the partials - B=8: 3.28 vs 3.24, B=32: 4.80 vs 4.52, e4m3 B=8: 2.40 vs 2.36.  So: fused only
-        # without a QKV split and at small batch.
-        fa = os.environ.get("UMV_DECODE_FUSE_ATTN", "auto")
-        self.fuse_attn = hd == 128 and ((sq == 1 and B <= 8) if fa == "auto" else fa not in ("0", ""))
+        # (q/k norm + RoPE + KV append folded into the attention kernel - umv_attn_decode_fused of experimental/ - wins only when the
+        # QKV GEMM is not split: B = 8: 3.32 vs 3.39 ms without a split, 3.28 vs 3.24 with the default 3-way split, B = 32: 4.80 vs
+        # 4.52; the default path splits, so the step always runs umv_qkv_post + umv_attn_varlen)
         self.do_sample, self.temperature, self.seed = bool(do_sample), float(temperature), int(seed)
         self.steps_done = 0
         self.graph = None
@@ -155,14 +151,10 @@ class DecodeSession:
             else:
                 ops.gemm(self.x, qkv_w, out=self.qkv)
                 part = {}
-            if self.fuse_attn:   # q/k norm + RoPE + KV append inside the attention kernel: one launch less per layer
-                ops.attn_decode_fused(self.qkv, self.o, c.slabs[l], self.cu_q, self.kv_len, self.tok_pos, nq, nkv, hd,
-                                      cfg.rms_eps, lw.q_norm, lw.k_norm, w.cos, w.sin, self.nsplit, self.ws, **part)
-            else:
-                ops.qkv_post(None if part else self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
-                             cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin, **part)
-                ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
-                              self.nsplit, self.ws)
+            ops.qkv_post(None if part else self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
+                         cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin, **part)
+            ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
+                          self.nsplit, self.ws)
             # ---- o_proj + residual, then the post-attention norm
             if so > 1:
                 ops.gemm_splitk(self.o, lw.o, self.p_h[:so], so)

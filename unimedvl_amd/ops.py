@@ -159,68 +159,6 @@ class PackedLinear:
         return self.wp.numel() * 2
 
 
-class DecodeLinear:
-    """Decode image of a PackedLinear (include/unimedvl_hip.h "decode GEMM"): one contiguous slab of th-row tiles per
-    CU for the persistent M <= 16 weight-streaming kernel.  Built once per weight; e4m3 when the source has an fp8 image."""
-
-    __slots__ = ("wd", "scale", "bias", "N", "K", "swiglu", "fp8", "layout")
-
-    def __init__(self, lin, n_cus=None):
-        lib = _lib.load_experimental()
-        dev = (lin.w8 if lin.w8 is not None else lin.wp).device
-        if n_cus is None:
-            n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        if lin.th != 16:
-            raise _lib.UmvError("DecodeLinear needs the standard 16-row image")
-        self.N, self.K, self.swiglu, self.bias = lin.N, lin.K, lin.swiglu, lin.bias
-        self.fp8 = lin.w8 is not None
-        rows = lin.N // 2 if lin.swiglu else lin.N
-        self.layout = _lib.DecodeLayout()
-        _lib.check_exp(lib.umv_decode_layout_for(rows, n_cus, C.byref(self.layout)), "umv_decode_layout_for")
-        nbytes = lib.umv_decode_image_bytes(lin.K, int(lin.swiglu), int(self.fp8), C.byref(self.layout))
-        self.wd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        L = self.layout
-        self.scale = torch.empty(L.G * L.tpw * (2 if lin.swiglu else 1) * 16, dtype=torch.float32, device=dev) if self.fp8 else None
-        src = lin.w8 if self.fp8 else lin.wp
-        _lib.check_exp(lib.umv_repack_weight_decode(_p(src), _p(lin.scale) if self.fp8 else None, _p(self.wd), _p(self.scale), rows, lin.K,
-                                           int(lin.swiglu), int(self.fp8), C.byref(self.layout), _stream()), "umv_repack_weight_decode")
-
-    def nbytes(self):
-        return self.wd.numel()
-
-
-def gemm_decode(x, dlin, out=None, *, M=None, residual=None, row_idx=None, use_bias=True, norm_w=None, norm_eps=1e-6):
-    """out = epilogue(x @ W^T) for M <= 16 rows from a DecodeLinear; norm_w fuses Qwen2RMSNorm(x) * norm_w (K <= 4096).
-    Bit-identical to gemm() on the same weight."""
-    lib = _lib.load_experimental()
-    _req(x, BF16, "x")
-    assert x.stride(-1) == 1
-    M = x.shape[0] if M is None else M
-    flags = 0
-    if dlin.bias is not None and use_bias:
-        flags |= EPI_BIAS
-    if dlin.swiglu:
-        flags |= EPI_SWIGLU
-    if residual is not None:
-        flags |= EPI_RESIDUAL
-    n_out = dlin.N // 2 if dlin.swiglu else dlin.N
-    if out is None:
-        assert row_idx is None, "row-indexed GEMM writes into a caller-provided buffer"
-        out = torch.empty((x.shape[0], n_out), dtype=BF16, device=x.device)
-    a = GemmArgs(
-        x=x.data_ptr(), ldx=x.stride(0), wp=dlin.wd.data_ptr(),
-        bias=dlin.bias.data_ptr() if (flags & EPI_BIAS) else None,
-        residual=residual.data_ptr() if residual is not None else None,
-        ldr=residual.stride(0) if residual is not None else 0,
-        out=out.data_ptr(), ldo=out.stride(0),
-        row_idx=row_idx.data_ptr() if row_idx is not None else None,
-        M=M, N=dlin.N, K=dlin.K, epilogue=flags,
-        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=0,
-        w_scale=dlin.scale.data_ptr() if dlin.fp8 else None)
-    _lib.check_exp(lib.umv_gemm_decode(C.byref(a), C.byref(dlin.layout), int(dlin.fp8), _stream()), "umv_gemm_decode")
-    return out
-
-
 def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
          norm_w=None, norm_eps=1e-6, act8=False, argmax_partial=None):
     """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
@@ -498,11 +436,11 @@ def attn_workspace(nseg, nq, hd, max_q, nsplit, device):
 
 
 def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None, k_packed=None,
-              experimental32=False):
+              _entry=None):
     """q: [T, nq*hd] or [T, nq, hd] rows, possibly a column slice of a wider buffer (row stride = q.stride(0)).
     k_packed: [T, nkv*hd] column slice holding K row-aligned with q (cache-less self-attention): the K slab is not read.
-    experimental32: run umv_attn_prefill32 of the EXPERIMENTAL library instead (hd 128, nsplit 1; tests / tools only)."""
-    lib = _lib.load_experimental() if experimental32 else _lib.load()
+    _entry: (function, checker, name) of another library taking the same umv_attn_args (experimental/ops.py; tests / tools only)."""
+    lib = _lib.load()
     _req(q, BF16, "q")
     if q.stride(-1) != 1 or (q.dim() == 3 and q.stride(1) != hd):
         raise _lib.UmvError("attention: q rows must be contiguous [nq * hd] runs")
@@ -522,34 +460,11 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
         k_slab=k_ptr, vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
         causal=int(bool(causal)), max_q=max_q, max_kv=max_kv, nsplit=nsplit,
         workspace=None if workspace is None else workspace.data_ptr(), q_row_stride=q.stride(0), k_key_stride=k_key_stride, **strides)
-    if experimental32:
-        _lib.check_exp(lib.umv_attn_prefill32(C.byref(a), _stream()), "umv_attn_prefill32")
+    if _entry is not None:
+        fn, chk, name = _entry
+        chk(fn(C.byref(a), _stream()), name)
         return out
     check(lib.umv_attn_varlen(C.byref(a), _stream()), "umv_attn_varlen")
-    return out
-
-
-def attn_decode_fused(qkv, out, slab, cu_q, kv_len, tok_pos, nq, nkv, hd, eps, q_norm, k_norm, cos_tab, sin_tab, nsplit=1,
-                      workspace=None, partials=None, bias=None):
-    """One decode step: q/k norm + RoPE + KV append + attention over kv_len keys, from the raw fused QKV rows (`qkv` bf16)
-    or from the fp32 partial sums [n_splits, B, (nq+2nkv)*hd] of a split-K QKV GEMM (`partials`, + `bias`)."""
-    lib = _lib.load_experimental()
-    extra = {}
-    if partials is not None:
-        _req(partials, torch.float32, "partials")
-        if partials.dim() != 3 or partials.stride(2) != 1:
-            raise _lib.UmvError("attn_decode_fused: partials must be [n_splits, B, (nq+2nkv)*hd] with unit column stride")
-        extra = dict(qkv=None, ld_qkv=partials.stride(1), qkv_partials=partials.data_ptr(), n_splits=partials.shape[0],
-                     split_stride=partials.stride(0), qkv_bias=None if bias is None else bias.data_ptr())
-    else:
-        _req(qkv, BF16, "qkv")
-        extra = dict(qkv=qkv.data_ptr(), ld_qkv=qkv.stride(0))
-    a = _lib.AttnDecodeArgs(
-        out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
-        tok_pos=tok_pos.data_ptr(), q_norm_w=q_norm.data_ptr(), k_norm_w=k_norm.data_ptr(), cos_tab=cos_tab.data_ptr(),
-        sin_tab=sin_tab.data_ptr(), k_slab=slab.k.data_ptr(), vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
-        eps=eps, nsplit=nsplit, workspace=None if workspace is None else workspace.data_ptr(), **extra, **slab.strides())
-    _lib.check_exp(lib.umv_attn_decode_fused(C.byref(a), _stream()), "umv_attn_decode_fused")
     return out
 
 
@@ -602,14 +517,3 @@ def cfg_renorm_euler(x_t, v_t, v_text, v_img, rows, seg_off, nseg, s_text, s_img
     check(lib.umv_cfg_renorm_euler(_p(x_t), _p(v_t), _p(v_text), _p(v_img), v_t.stride(0), _p(rows), _p(seg_off), nseg,
                                    float(s_text), float(s_img), float(renorm_min), int(rtype), float(dt), x_t.shape[1],
                                    _stream()), "umv_cfg_renorm_euler")
-
-
-def prefetch(t, nbytes=None, offset=0, blocks=128, stream=None):
-    """Pull `nbytes` of tensor `t` (from byte `offset`) into L2 / Infinity Cache on `stream` (default: current)."""
-    lib = _lib.load_experimental()
-    total = t.numel() * t.element_size()
-    nbytes = total - offset if nbytes is None else min(nbytes, total - offset)
-    if nbytes <= 0:
-        return
-    st = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
-    _lib.check_exp(lib.umv_prefetch(C.c_void_p(t.data_ptr() + offset), nbytes, blocks, None, st), "umv_prefetch")
