@@ -769,6 +769,27 @@ def main():
                 f = prof.get("pmc", {}).get(name, {}).get("FETCH_SIZE", {}).get("avg_kib")
                 return v["avg_us"], v["calls"], (f * 2048.0 if f else None)
         return None
+    def stage_counters(stage):
+        """MFMA-side counters of the busiest tiled-GEMM kernel of a stage (tools/roofline_profile.sh: rocprofv3 --pmc passes over
+        tools/stage_profile.py <stage>, same stamp rule as `traffic`); None when the profile is absent / stale"""
+        rows = (prof or {}).get("stage_pmc", {}).get(stage) or {}
+        best = None
+        for name, c in rows.items():
+            if "gemm_tiled" not in name or "MfmaUtil" not in c:
+                continue
+            if best is None or c["MfmaUtil"]["n"] > rows[best]["MfmaUtil"]["n"]:
+                best = name
+        if best is None:
+            return None
+        c = rows[best]
+        out_c = {"kernel": best.split("Ev13")[0].replace("_Z17gemm_tiled_kernelI", "gemm_tiled<").replace("ELi", ",").replace("Li", "") + ">",
+                 "dispatches": c["MfmaUtil"]["n"], "mfma_util_pct": round(c["MfmaUtil"]["avg"], 1)}
+        if "LdsUtil" in c:
+            out_c["lds_util_pct"] = round(c["LdsUtil"]["avg"], 1)
+        if "SQ_WAIT_INST_LDS" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"]["avg"]:
+            out_c["wait_inst_lds_per_busy_cycle"] = round(c["SQ_WAIT_INST_LDS"]["avg"] / c["SQ_BUSY_CYCLES"]["avg"], 3)
+        out_c["source"] = "profiles/roofline_profile_latest.json (rocprofv3 --pmc, own passes, same kernel sources as this library)"
+        return out_c
     dom_sub = "gemm_skinny_kernelILi1ELi2ELi4E"
     dom = prof_kernel(dom_sub)
     avg_us_replay = avg_us
@@ -828,30 +849,34 @@ def main():
         if v is not None:
             small.append({"kernel": label, "avg_launch_us": round(v[0], 2), "launches_profiled": v[1]})
 
-    # ---- ViT encode (MFMA-bound leg of the prefill): 8 x 448x448 through the SigLIP tower + connector
-    vit = None
-    if args.config == "full" and not args.no_vit:
-        gi_v, _, _ = model.prepare_vit_images([0] * B, [0] * B, images, lambda x: x, new_token_ids)
-        px = gi_v["packed_vit_tokens"].to(dev)
+    # ---- ViT encode (MFMA-bound leg of the prefill): B x 448x448 through the SigLIP tower + connector
+    def vit_leg(images_v, reps=3):
+        Bv = len(images_v)
+        gi_v, _, _ = model.prepare_vit_images([0] * Bv, [0] * Bv, images_v, lambda x: x, new_token_ids)
+        px = gi_v["packed_vit_tokens"].to(dev)          # the patch tokens, or (device patchify) the images: resident either way
         pos_v = gi_v["packed_vit_position_ids"].to(dev)
         model.encode_vit(px, pos_v, gi_v["vit_token_seqlens"])
         torch.cuda.synchronize()
         v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         v0.record()
-        for _ in range(3):
+        for _ in range(reps):
             model.encode_vit(px, pos_v, gi_v["vit_token_seqlens"])
         v1.record()
         torch.cuda.synchronize()
-        vit_ms = v0.elapsed_time(v1) / 3
-        n_tok = px.shape[0]
+        vit_ms = v0.elapsed_time(v1) / reps
+        n_tok = int(gi_v["vit_token_seqlens"].sum())
         vh, vi = cfg.vit_hidden, cfg.vit_inter
         flops = 2 * n_tok * (cfg.vit_layers * (4 * vh * vh + 2 * vh * vi) + 3 * cfg.patch ** 2 * vh) \
-            + cfg.vit_layers * 4 * (n_tok // B) ** 2 * vh * B + 2 * n_tok * (vh * cfg.hidden + cfg.hidden * cfg.hidden)
-        vit = {"images_per_s": round(B / (vit_ms * 1e-3), 1), "ms_per_batch": round(vit_ms, 3), "batch": B,
-               "tflops": round(flops / (vit_ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (vit_ms * 1e-3) / 2.5e15, 4),
-               # the other roofline, for completeness (BASELINE.json pairs ViT with HBM): weights once + pixel input + output
-               "hbm_frac_of_8000": round((0.79e9 + n_tok * (3 * cfg.patch ** 2 * 4 + cfg.hidden * 2)) / (vit_ms * 1e-3) / 8e12, 5),
-               "note": "ViT tower + connector, 1024 patches/image; MFMA-bound (intensity ~700 flop/B), hd-72 attention included"}
+            + cfg.vit_layers * 4 * (n_tok // Bv) ** 2 * vh * Bv + 2 * n_tok * (vh * cfg.hidden + cfg.hidden * cfg.hidden)
+        return {"images_per_s": round(Bv / (vit_ms * 1e-3), 1), "ms_per_batch": round(vit_ms, 3), "batch": Bv,
+                "tflops": round(flops / (vit_ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (vit_ms * 1e-3) / 2.5e15, 4),
+                # the other roofline, for completeness (BASELINE.json pairs ViT with HBM): weights once + pixel input + output
+                "hbm_frac_of_8000": round((0.79e9 + n_tok * (3 * cfg.patch ** 2 * 4 + cfg.hidden * 2)) / (vit_ms * 1e-3) / 8e12, 5),
+                "patchify": "device (umv_patchify_f32_bf16, inside the timed region)" if getattr(model, "device_patchify", False) else "host (before the timed region)",
+                "note": "ViT tower + connector, 1024 patches/image; MFMA-bound (intensity ~700 flop/B), hd-72 attention included"}
+    vit = vit_leg(images) if args.config == "full" and not args.no_vit else None
+    if vit is not None:
+        vit["mfma_counters"] = stage_counters("vit")
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
@@ -918,11 +943,16 @@ def main():
         l3 = None
         torch.cuda.empty_cache()
         sess = cache = None
+        if not args.no_vit:      # the tower where its GEMMs fill the chip: the 32 images of one GPU's configs[3] shard in one pass
+            out["vit_encode_b32"] = vit_leg(images3)
+            torch.cuda.empty_cache()
     if want_t2i:
         del sess, cache
         torch.cuda.empty_cache()
         if args.config == "full":
             out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, num_timesteps=args.t2i_steps)
+            out["t2i"]["mfma_counters"] = stage_counters("t2i")
+            out["prefill_mfma_counters"] = stage_counters("prefill")
         else:
             out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, batch=2, hw=64, prompt_len=8, num_timesteps=6)
     if not args.no_fp8 and not lw.fp8 and args.config == "full":

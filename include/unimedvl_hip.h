@@ -178,6 +178,10 @@ int umv_sample_bf16(const uint16_t* logits, int64_t ld, int64_t* out_ids, int M,
  * the patch-embed linear, siglip_navit.py:190) */
 int umv_cast_pad_f32_bf16(const float* x, int64_t ldx, uint16_t* out, int64_t ldo, int T, int K, int Kp,
                           umv_stream_t stream);
+/* patchify (data/data_utils.py:43-50) + that cast on the device: transformed image [C, H, W] fp32 -> tokens
+ * [(H/p)*(W/p), Kp] bf16, column (pp*p + qq)*C + c of token (ph, pw) = image[c][ph*p + pp][pw*p + qq], zero padded to Kp.
+ * Replaces the host-side permute of prepare_vit_images (bagel.py:540-548) on the engine's own path. */
+int umv_patchify_f32_bf16(const float* img, int C, int H, int W, int p, uint16_t* out, int64_t ldo, int Kp, umv_stream_t stream);
 
 /* ------------------------------------------------------------------ attention
  * KV slab layout (replaces NaiveCache's re-merged [sum K, kvh, hd] tensors,

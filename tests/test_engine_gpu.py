@@ -83,6 +83,58 @@ def test_vit_tower(engine):
     close(buf, g["connector_out"], what="connector_out")
 
 
+def test_device_patchify_equals_host_patchify(engine):
+    """umv_patchify_f32_bf16 (the engine's own path: prepare_vit_images hands over the images, data_utils.PackedVitImages) against
+    the reference's host-side patchify (data_utils.py:43-50) + the bf16 cast: the tokens bit for bit, and a ragged two-image
+    image prefill whose KV must be bit-identical either way; the graph-replay path refreshes its image buffers in place."""
+    from unimedvl_amd import ops
+    from unimedvl_amd.data_utils import PackedVitImages, patchify
+    from unimedvl_amd.kvcache import NaiveCache
+    g = torch.Generator().manual_seed(77)
+    imgs = [torch.randn(3, 42, 56, generator=g), torch.randn(3, 28, 70, generator=g)]
+    for im in imgs:
+        want = torch.zeros((im.shape[1] // 14) * (im.shape[2] // 14), 608, dtype=BF16)
+        want[:, :588] = patchify(im, 14).to(BF16)
+        got = torch.full(want.shape, 7.0, dtype=BF16, device="cuda")
+        ops.patchify(im.cuda(), got, 14)
+        assert torch.equal(got.cpu(), want)
+    assert engine.device_patchify
+    L = engine.cfg.layers
+    outs = []
+    for dp in (True, False):
+        engine.device_patchify = dp
+        try:
+            gi, kvl, rope = engine.prepare_vit_images([0, 0], [0, 0], imgs, lambda x: x, NEW_TOKEN_IDS)
+        finally:
+            engine.device_patchify = True
+        assert isinstance(gi["packed_vit_tokens"], PackedVitImages) == dp
+        # whoever asks gets the reference's tensor
+        assert torch.equal(torch.as_tensor(gi["packed_vit_tokens"][:]), torch.cat([patchify(im, 14) for im in imgs], 0))
+        assert tuple(gi["packed_vit_tokens"].shape) == (12 + 10, 588)
+        cache = engine.forward_cache_update_vit(NaiveCache(L), **gi)
+        outs.append([cache.packed_keys(l).clone() for l in range(L)] + [cache.packed_values(L - 1).clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # reserved cache -> the image span replays from a HIP graph; the second request reuses the plan's image buffer
+    if engine.prefill_graph:
+        keys = []
+        for im in (imgs[0], imgs[0] * 0.5):
+            cache = NaiveCache(L)
+            cache.reserve(1, 64, engine.cfg.kv_heads, engine.cfg.head_dim, engine.device)
+            ref = NaiveCache(L)
+            gi, _, _ = engine.prepare_vit_images([0], [0], [im], lambda x: x, NEW_TOKEN_IDS)
+            cache = engine.forward_cache_update_vit(cache, **gi)
+            engine.device_patchify = False
+            try:
+                gi2, _, _ = engine.prepare_vit_images([0], [0], [im], lambda x: x, NEW_TOKEN_IDS)
+            finally:
+                engine.device_patchify = True
+            ref = engine.forward_cache_update_vit(ref, **gi2)
+            assert torch.equal(cache.packed_keys(L - 1), ref.packed_keys(L - 1))
+            keys.append(cache.packed_keys(L - 1).clone())
+        assert not torch.equal(keys[0], keys[1])
+
+
 def test_vqa_b1(engine):
     from unimedvl_amd.kvcache import NaiveCache
     g = load_golden("vqa_b1")

@@ -326,7 +326,8 @@ def test_configs2_t2i_256_fifty_timesteps(fw):
         rng = otrace[-1].float().abs().max().item()
         print(f"configs[2] 50 timesteps, sample {b}: latent |diff| max per step: step 1 {mx[0]:.4f}, 10 {mx[9]:.4f}, 25 {mx[24]:.4f}, "
               f"40 {mx[39]:.4f}, 49 {mx[48]:.4f}; worst {max(mx):.4f}; mean at the last step {mean[-1]:.5f} (latent range {rng:.2f})")
-        # measured (MI355X, round 4): see DESIGN.md section 3; bounds at ~2x
+        # measured (MI355X, round 4): the deviation grows steadily over the 49 steps - max 0.0006 after step 1, 0.003 after 10, 0.005 after
+        # 25, 0.011 after 40, 0.0131 / 0.0137 after 49 (two samples), mean 0.0025 at the end, on a latent range of 5.8; bounds at ~2x
         assert max(mx) <= T2I50_LAT_MAX and mean[-1] <= T2I50_LAT_MEAN, f"sample {b}: latent max {max(mx)} mean(last) {mean[-1]}"
         mine = lat[b] if isinstance(lat, (list, tuple)) else lat[b * n_tok:(b + 1) * n_tok]
         px = vae.decode_tokens_to_uint8(mine, (hw, hw), model.latent_downsample, model.latent_patch_size).cpu()
@@ -336,12 +337,14 @@ def test_configs2_t2i_256_fifty_timesteps(fw):
         dist = {k: round(100 * (diff <= k).float().mean().item(), 3) for k in (0, 1, 2, 4, 8, 16)}
         print(f"configs[2] 50 timesteps, sample {b}: END-TO-END uint8 pixels (engine latent -> engine VAE vs oracle latent -> oracle VAE): "
               f"% within k grey levels {dist}, max {diff.max().item()}, mean {diff.float().mean().item():.3f}")
-        assert dist[4] >= T2I50_PIX_WITHIN4 and diff.max().item() <= T2I50_PIX_MAX, f"pixels sample {b}: {dist}, max {diff.max().item()}"
+        # measured: 48.5-48.9 % exact, 88.2-88.4 % within 1, 99.06-99.08 % within 2, 99.997 % within 4, max 5 levels (SURVEY 8c's +-2 on >= 99 %)
+        assert dist[2] >= T2I50_PIX_WITHIN2 and dist[4] >= T2I50_PIX_WITHIN4 and diff.max().item() <= T2I50_PIX_MAX, \
+            f"pixels sample {b}: {dist}, max {diff.max().item()}"
     assert gen.lens == cfg_img.lens == kvl and cfg_text.seq_lens == 0, "flow passes must not commit KV"
 
 
 # bounds of the 50-timestep test (measured distribution in DESIGN.md section 3)
-T2I50_LAT_MAX, T2I50_LAT_MEAN, T2I50_PIX_WITHIN4, T2I50_PIX_MAX = 0.5, 0.05, 90.0, 64
+T2I50_LAT_MAX, T2I50_LAT_MEAN, T2I50_PIX_WITHIN2, T2I50_PIX_WITHIN4, T2I50_PIX_MAX = 0.03, 0.006, 98.5, 99.9, 10
 
 
 def test_t2i_packed_batch_global_renorm_reference_semantics(fw):
@@ -390,7 +393,9 @@ def test_t2i_packed_batch_global_renorm_reference_semantics(fw):
     gap = (out["per_sample"][-1] - otrace[-1].float()).abs().max().item()
     print(f"packed-batch global renorm (reference semantics), B = 2, {steps - 1} guided Euler steps: latent |diff| vs the oracle's packed "
           f"batch max {worst:.4f} mean {mean:.5f}; the per-sample default differs from the packed reference by {gap:.3f}")
-    assert worst <= 0.25 and mean <= 0.02, f"reference batch semantics: latent max {worst} mean {mean}"
+    # measured (MI355X, round 4): max 0.0801, mean 0.0132 over the 5 guided steps (the second sample's noise is 3x, so are its latents);
+    # the per-sample default is 0.473 away from the packed reference; bounds at 2x
+    assert worst <= 0.16 and mean <= 0.027, f"reference batch semantics: latent max {worst} mean {mean}"
     assert gap > 4 * worst, "per-sample and packed-batch renorm should differ visibly on this input"
 
 

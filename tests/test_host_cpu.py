@@ -101,6 +101,38 @@ def test_transforms_and_rgb():
     assert t.shape[0] == 3 and t.shape[1] % 16 == 0 and t.shape[2] % 16 == 0 and float(t.max()) == 1.0
 
 
+def test_packed_vit_images_is_the_reference_tensor_for_whoever_asks():
+    """data_utils.PackedVitImages (what prepare_vit_images returns as "packed_vit_tokens" when the engine patchifies on the device)
+    must behave as the reference's tensor: same values through torch functions, indexing, attributes; .to() keeps the images."""
+    from unimedvl_amd.data_utils import PackedVitImages, patchify
+    from unimedvl_amd.prep import BagelPrep
+    g = torch.Generator().manual_seed(5)
+    imgs = [torch.randn(3, 28, 42, generator=g), torch.randn(3, 56, 14, generator=g)]
+    ref = torch.cat([patchify(im, 14) for im in imgs], 0)
+    pv = PackedVitImages(imgs, 14)
+    assert tuple(pv.shape) == tuple(ref.shape) and len(pv) == ref.shape[0] and pv.size(1) == 588 and pv.token_counts() == [6, 4]
+    assert torch.equal(pv, ref) and torch.equal(pv[3:7], ref[3:7]) and torch.equal(torch.cat([pv, pv], 0), torch.cat([ref, ref], 0))
+    assert pv.dtype == torch.float32 and float(pv.abs().sum()) == float(ref.abs().sum())
+    assert torch.equal((pv * 2.0), ref * 2.0) and torch.equal(pv.numpy().sum() + torch.zeros(()), ref.numpy().sum() + torch.zeros(()))
+    moved = pv.to("cpu")
+    assert isinstance(moved, PackedVitImages) and torch.equal(moved.tokens(), ref)
+
+    class P(BagelPrep):                       # the prep mix-in alone (no device): both contracts from the same call
+        vit_patch_size, vit_max_num_patch_per_side, device_patchify = 14, 70, False
+
+        def get_flattened_position_ids(self, h, w, p, max_num_patches_per_side):
+            from unimedvl_amd.data_utils import get_flattened_position_ids_extrapolate as f
+            return f(h, w, p, max_num_patches_per_side)
+    prep = P.__new__(P)
+    ntid = dict(bos_token_id=1, eos_token_id=2, start_of_image=3, end_of_image=4)
+    a, kv_a, rope_a = prep.prepare_vit_images([0, 5], [0, 5], imgs, lambda x: x, ntid)
+    prep.device_patchify = True
+    b, kv_b, rope_b = prep.prepare_vit_images([0, 5], [0, 5], imgs, lambda x: x, ntid)
+    assert kv_a == kv_b and rope_a == rope_b and isinstance(b["packed_vit_tokens"], PackedVitImages)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_c_abi_exports_every_declared_symbol():
     """Every function include/unimedvl_hip.h declares must be exported by the built library and
     bound by the ctypes layer (no compute call: this runs without a GPU)."""

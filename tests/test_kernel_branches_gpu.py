@@ -195,12 +195,15 @@ def test_gemm_splitk_partials_sum_to_fp32_reference(ops, M, N, K, S):
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 100, 2048, 266), (515, 1000, 1152, 268), (1000, 4300, 1152, 266), (777, 250, 1024, 270),
-                                          (515, 1000, 1160, 288), (130, 300, 3584, 288)])   # 288 x 128: 26 staging pieces on 8 waves
+                                          (515, 1000, 1160, 288), (130, 300, 3584, 288),    # 288 x 128: 26 staging pieces on 8 waves
+                                          (300, 100, 2048, -266), (777, 250, 1024, -270)])  # negative: the half-line staging (UMV_GEMM_XLINE=0)
 def test_gemm_lds_epilogue_ragged_and_unaligned(ops, M, N, K, tile, monkeypatch):
     """The whole-row LDS epilogue of the tiled kernels (gemm_epilogue.h::epi_wave_tile_lds) on everything that leaves its 16-byte
     fast path: N not a multiple of 8 (the last 16-byte chunk of a row is partial), an output / residual row pitch that is not a
     multiple of 8 elements and a base pointer 2 bytes off 16-byte alignment (element stores, element residual loads), M with a
     ragged last tile, row-indexed scatter.  Against fp32 matmul; rows and columns outside the result must stay untouched."""
+    xline = "0" if tile < 0 else "1"
+    tile = abs(tile)
     monkeypatch.setenv("UMV_GEMM_TILE", str(tile))
     import subprocess as sp
     code = f"""
@@ -232,8 +235,46 @@ r2 = torch.nn.functional.gelu((_mm(x, w) + b.float()).to(BF16), approximate='tan
 check_bf16(o2, r2, 1, 0.97, 'ragged gelu', two_roundings=True)
 print('OK')
 """
-    r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, UMV_GEMM_TILE=str(tile)))
+    r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, UMV_GEMM_TILE=str(tile), UMV_GEMM_XLINE=xline))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tile", [266, 268, 384, 270])
+def test_full_line_x_staging_bit_identical(ops, tile):
+    """The default staging of the interleaved tiles (gemm.hip SCHED = 3: x in full 128-byte lines through an XOR-swizzled row-major
+    ring, k-step pairs) against the half-line staging it replaced (UMV_GEMM_XLINE=0): the same MFMAs on the same operands in the
+    same order, so every output bit must agree - full tiles, ragged M / N, K that is not a multiple of 64 or of 32 (zero-filled
+    tail chunks), an odd number of k-steps, K shorter than the prologue, row-indexed A / C and the SwiGLU epilogue."""
+    import subprocess as sp
+    code = f"""
+import hashlib, sys, math, torch
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+from unimedvl_amd import ops
+from test_kernel_branches_gpu import rnd, BF16
+for M, N, K in ((2048, 4608, 3584), (8192, 1152, 4304), (1000, 1152, 1160), (300, 520, 1096), (700, 3584, 96), (515, 1152, 4304), (260, 300, 40), (4099, 777, 2080)):
+    x = rnd((M, K), 1); w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
+    lin = ops.PackedLinear.from_weight(w, b)
+    res = rnd((M, N), 4)
+    out = ops.gemm(x, lin, residual=res)
+    print('sha', M, N, K, hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+    T = M + 9
+    rows = torch.randperm(T, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))[:M].sort().values.to(torch.int32)
+    xs = torch.zeros((T, K), dtype=BF16, device='cuda'); xs[rows.long()] = x
+    o2 = torch.zeros((T, N), dtype=BF16, device='cuda')
+    ops.gemm(xs, lin, out=o2, M=M, row_idx=rows)
+    print('sha rows', M, N, K, hashlib.sha256(o2.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+g, u = rnd((1024, 2048), 6, 0.02), rnd((1024, 2048), 7, 0.02)
+lin = ops.PackedLinear.from_gate_up(g, u)
+o3 = ops.gemm(rnd((2050, 2048), 8), lin)
+print('sha swiglu', hashlib.sha256(o3.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+"""
+    shas = {}
+    for xl in ("0", "1"):
+        r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, UMV_GEMM_TILE=str(tile), UMV_GEMM_XLINE=xl))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        shas[xl] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
+        assert len(shas[xl]) == 17
+    assert shas["0"] == shas["1"], [(a, b) for a, b in zip(shas["0"], shas["1"]) if a != b]
 
 
 # ---------------------------------------------------------------------------------------------------------- attention

@@ -19,9 +19,38 @@ python tools/rocpd_stats.py "$DB" gpurun_out/${TAG}_decode_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d gpurun_out/$TAG/$C -o pmc -- python bench.py $ARGS --steps 4 --warmup 1 > gpurun_out/$TAG/$C/bench.log 2>&1 || true
 done
+# MFMA-bound legs: counters of the dominant kernels of the ViT tower, the image-span prefill and the text-to-image leg
+# (one rocprofv3 pass per counter set, --kernel-trace only), attached by bench.py to its vit_encode / t2i objects
+if [ -z "$SKIP_STAGE_PMC" ]; then
+for ST in vit prefill t2i; do
+  for C in "MfmaUtil" "LdsUtil" "SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"; do
+    D=gpurun_out/$TAG/stage_${ST}_$(echo $C | tr ' ' '_')
+    mkdir -p $D
+    REPS=3 rocprofv3 --pmc $C --kernel-trace -d $D -o pmc -- python tools/stage_profile.py $ST > $D/log.txt 2>&1 || true
+  done
+done
+fi
 python - <<PY
 import csv, glob, json, sqlite3
 tag = "$TAG"
+stage_pmc = {}
+for st in ("vit", "prefill", "t2i"):
+    rows = {}
+    for d in glob.glob(f"gpurun_out/{tag}/stage_{st}_*"):
+        dbs = glob.glob(d + "/*results.db")
+        if not dbs:
+            continue
+        cur = sqlite3.connect(dbs[0]).cursor()
+        q = """select s.kernel_name, c.name, count(*), avg(p.value) from rocpd_pmc_event p
+               join rocpd_kernel_dispatch d on p.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+               join rocpd_info_pmc c on p.pmc_id = c.id where s.kernel_name like '%gemm_tiled%' or s.kernel_name like '%attn_prefill%'
+               group by 1, 2"""
+        try:
+            for name, cname, n, avg in cur.execute(q):
+                rows.setdefault(name, {})[cname] = dict(n=n, avg=avg)
+        except Exception as e:
+            rows["error"] = str(e)
+    stage_pmc[st] = rows
 stamp = open("unimedvl_amd/lib/build.stamp").read().strip()
 kern = {}
 for r in csv.DictReader(open(f"gpurun_out/{tag}_decode_kernel_stats.csv")):
@@ -44,7 +73,7 @@ try:
     line = json.loads(open(f"gpurun_out/{tag}_decode_line_under_rocprof.json").read().strip().splitlines()[-1])
 except Exception:
     pass
-out = dict(code_stamp=stamp, tag=tag, kernels=kern, pmc=pmc,
+out = dict(code_stamp=stamp, tag=tag, kernels=kern, pmc=pmc, stage_pmc=stage_pmc,
            bench_line_under_rocprof={k: line.get(k) for k in ("value", "ms_per_step", "steps", "config")},
            correction="traffic = FETCH_SIZE (KiB) x 1024 x 2: gfx950's rocprofv3 tallies the 128-byte requests of a 16 B/lane coalesced stream at 64 B "
                       "(MI355X_MICROARCH.md 'HBM'); WRITE_SIZE is uncalibrated and reported raw (KiB)",

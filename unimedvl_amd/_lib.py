@@ -90,6 +90,7 @@ _SIGS = {
                                   C.c_void_p]),
     "umv_cast_pad_f32_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
+    "umv_patchify_f32_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "umv_qkv_post": (C.c_int, [C.POINTER(QkvPostArgs), C.c_void_p]),
     "umv_attn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "umv_attn_varlen": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),

@@ -66,6 +66,10 @@ class Bagel(BagelPrep):
         self.eos_check_every = 16
         import os
         self.prefill_graph = os.environ.get("UMV_PREFILL_GRAPH", "1") not in ("0", "")   # graph replay of image spans into reserved caches
+        # prepare_vit_images hands the engine the transformed images and the patch tokens are made ON THE DEVICE (umv_patchify_f32_bf16);
+        # generation_input["packed_vit_tokens"] is then a data_utils.PackedVitImages, which still is the reference's tensor for
+        # anyone who asks (UMV_DEVICE_PATCHIFY=0: the reference's host-side permute, 4 ms per 448 x 448 image)
+        self.device_patchify = os.environ.get("UMV_DEVICE_PATCHIFY", "1") not in ("0", "")
         self._vit_graphs = {}
         self.prefill_graph_max = 8          # captured image-span graphs kept (one per cache and patch grid; ~0.1 GB of activations each)
         self.chat_cache_tokens = 0          # > 0: chat() prefills / decodes in one pooled, reserved cache of that capacity

@@ -23,6 +23,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file additions.  attention_prefill: MFMA destinations stay in VGPRs (the compiler's default parks the 64 O accumulators in
 # AGPRs and moves them out and back around every rescale)
 FILE_FLAGS = {"attention_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# UMV_GEMM_ABLATIONS=1: also instantiate the tiled GEMM's timing-only ablations and its 32x32x16 variant (UMV_GEMM_TILE=966x / 566...,
+# tools/r04_gemm_abl.sh); never in the default build
+if os.environ.get("UMV_GEMM_ABLATIONS", "0") not in ("0", ""):
+    FILE_FLAGS["gemm.hip"] = ["-DUMV_GEMM_ABLATIONS"]
 
 
 def _stamp():

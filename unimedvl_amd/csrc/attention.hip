@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     const int s = blockIdx.z;
     const int kh = blockIdx.y % a.nkv;
     const int split = blockIdx.y / a.nkv;
-    const int qt = blockIdx.x * 4 + wave;
+    const int qt = blockIdx.x * (int)(blockDim.x >> 6) + wave;      // 1..4 q-tiles (waves) per workgroup, see the launcher
     const int q0 = a.cu_q[s];
     const int Lq = a.cu_q[s + 1] - q0;
     const int Lk = a.kv_len[s];
@@ -238,7 +238,10 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     const int G = a.nq / a.nkv;
     const int QPT = 16 / G > 0 ? 16 / G : 1;
     const int qtiles = (a.max_q + QPT - 1) / QPT;
-    dim3 grid((qtiles + 3) / 4, a.nkv * a.nsplit, a.nseg), block(256);
+    // one wave per q-tile, up to four per workgroup: a decode step (max_q = 1) has ONE q-tile per (segment, kv head, split), so its
+    // workgroups are single waves (with 256 threads three of the four waves of each of the 544 workgroups only exited)
+    const int wpb = qtiles < 4 ? qtiles : 4;
+    dim3 grid((qtiles + wpb - 1) / wpb, a.nkv * a.nsplit, a.nseg), block(64 * wpb);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
     if (a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72) && umv_attn_prefill_enabled())

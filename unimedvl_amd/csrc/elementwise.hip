@@ -496,6 +496,34 @@ extern "C" int umv_cast_pad_f32_bf16(const float* x, int64_t ldx, uint16_t* out,
     return UMV_OK;
 }
 
+// ----------------------------------------------------------------------------- patchify on the device
+// patchify() of data_utils.py:43-50 + the fp32 -> bf16 cast autocast applies in front of the patch-embed linear (siglip_navit.py:190),
+// from the transformed [C, H, W] fp32 image: token (ph, pw), column (pp * p + qq) * C + c  =  image[c][ph * p + pp][pw * p + qq], columns
+// K = p * p * C .. Kp - 1 zero.  One workgroup per token; the host-side permute of the reference costs 4 ms per 448 x 448 image.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int C, int H, int W, int p, bf16_t* __restrict__ out, int64_t ldo,
+                                                       int Kp) {
+    const int nw = W / p;
+    const int tok = blockIdx.x, ph = tok / nw, pw = tok % nw;
+    const int K = p * p * C;
+    bf16_t* o = out + (int64_t)tok * ldo;
+    for (int col = threadIdx.x; col < Kp; col += blockDim.x) {
+        bf16_t v = 0;
+        if (col < K) {
+            const int c = col % C, t = col / C, qq = t % p, pp = t / p;
+            v = f2bf(img[((int64_t)c * H + ph * p + pp) * W + pw * p + qq]);
+        }
+        o[col] = v;
+    }
+}
+extern "C" int umv_patchify_f32_bf16(const float* img, int C, int H, int W, int p, uint16_t* out, int64_t ldo, int Kp, umv_stream_t stream) {
+    UMV_CHECK(img && out, UMV_ERR_ARG, "patchify: null pointer");
+    UMV_CHECK(C > 0 && p > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0, UMV_ERR_ARG, "patchify: image %d x %d x %d is not a whole number of %d-pixel patches", C, H, W, p);
+    UMV_CHECK(Kp >= p * p * C && ldo >= Kp, UMV_ERR_ARG, "patchify: Kp %d / ldo %lld too small for %d values per patch", Kp, (long long)ldo, p * p * C);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((H / p) * (W / p))), dim3(256), 0, (hipStream_t)stream, img, C, H, W, p, out, ldo, Kp);
+    UMV_LAUNCH_CHECK();
+    return UMV_OK;
+}
+
 // ----------------------------------------------------------------------------- q/k norm + RoPE + KV append
 // One wavefront per (token, head) over the nq + 2*nkv heads of the fused QKV row.
 // Lane i owns elements i*EPL.. of the first half and the matching ones of the second

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 #include "gemm_epilogue.h"
+#include <string.h>
 #include <stdlib.h>
 
 // ----------------------------------------------------------------------------- packing
@@ -736,7 +737,10 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     // LDS-DMA pieces per k-step and the counted s_waitcnt vmcnt(N) below stay exact.
     constexpr int NDUMMY = NW * TPW - NT_ALL;
     constexpr int BUF = NT_ALL * 1024;
-    constexpr int DUMPOFF = NBUF * BUF + (BN * 2 + 15) / 16 * 16;
+    // bytes of the staging area (the tile's bias sits behind it): NBUF whole-step buffers, or - SCHED = 3 - a 3-slot ring of W
+    // k-steps + a 3-slot ring of x k-step pairs
+    constexpr int STAGE_BYTES = (SCHED & 15) == 3 ? 3 * WTILES * 1024 + 3 * BM * 128 : NBUF * BUF;
+    constexpr int DUMPOFF = STAGE_BYTES + (BN * 2 + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];        // [NBUF][BUF]: W tiles [BN/16][KTS], then x tiles [BM/16][KTS]
     auto dst_of = [&](int buf, int f) -> char* { return (NDUMMY == 0 || f < NT_ALL) ? smem + buf * BUF + f * 1024 : smem + DUMPOFF + (f - NT_ALL) * 1024; };
     const int tid = threadIdx.x;
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     const int nt_base = nt_blk + wn * TN;
     // the tile's BN bias values wait in LDS behind the staging buffers: read after the main loop, a global load there would
     // expose its whole latency once per tile (the first barrier of the main loop orders this write before any read)
-    bf16_t* bias_lds = reinterpret_cast<bf16_t*>(smem + NBUF * BUF);
+    bf16_t* bias_lds = reinterpret_cast<bf16_t*>(smem + STAGE_BYTES);
     if ((a.epilogue & UMV_EPI_BIAS) && tid < BN) {
         const int n = nt_blk * 16 + tid;
         bias_lds[tid] = n < a.N ? a.bias[n] : (bf16_t)0;
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr bool PX = (SCHED & 15) == 3;     // paired x staging: see the SCH == 3 block below
+    constexpr bool PX = (SCHED & 15) == 3;     // full-line x staging: see the SCHED = 3 block below (own prologue)
 #pragma unroll
     for (int p = 0; p < (PX ? 0 : NBUF - 1); ++p) {
         if (p < nsteps) stage(p, p);
@@ -1024,27 +1028,30 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
                 for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(acc[t][j]));
         }
     } else if constexpr (PX) {
-        // SCHED = 3: the interleaved schedule of SCHED = 1 with the x pieces staged in PAIRS of k-steps.  An x piece gathers 16 rows
-        // x 64 bytes - HALF of a 128-byte line per row; the other half is the piece of the next k-step, a whole step (~0.8 us) later,
-        // when the line has long left the 32 KiB L1: every x line travels L2 -> L1 twice and holds a miss entry twice as long per
-        // byte as a W line (measured, 8192^3: x pieces read as contiguous KiB instead - wrong data, timing only - 827 -> 766 us; no
-        // x pieces at all 712; no W pieces 663; no pieces 535).  Here a wave issues the pieces of k-tiles t+3 and t+4 (an even /
-        // odd pair = the two halves of the same lines) of one 16-row tile back to back in the ODD step t - the second request meets
-        // the line in flight or in L1 - and none in even steps; W tiles are staged three steps ahead as before.  Same LDS image,
-        // same fragment reads, same MFMA order: results are bit-identical to SCHED = 1.  Every wave stages WPW W tiles per step and
-        // XPW x row-tiles per pair.  The body of step t computes on tile t (in registers) and reads the fragments of tile t + 1, so
-        // its head waits for tile t + 1:  even t -> W(t+1) came in body t-2 and behind it went x(t+2), x(t+3), W(t+2) of body t-1:
-        // 2 XPW + WPW pieces may still fly;  odd t -> x(t+1), W(t+1) came in body t-2 and only W(t+2) of body t-1 is behind them.
-        // Buffers: x(t+4) takes the buffer of tile t, free once every wave has passed the head barrier of body t.
-        constexpr int WPW = WTILES / NW, XPW = XTILES / NW;
-        static_assert(KTS == 1 && NBUF == 4 && WTILES % NW == 0 && XTILES % NW == 0 && NDUMMY == 0, "paired x staging: 4 buffers, even split of the tiles over the waves");
+        // SCHED = 3: the interleaved schedule of SCHED = 1 with the x operand staged in FULL 128-byte lines.  The 1 KiB x piece of
+        // SCHED = 1 gathers 16 rows x 64 bytes - half a line per row; the other half is fetched by the next k-step's piece, ~0.8 us
+        // later, when the line has long left the 32 KiB L1 - so an x byte costs twice the L1 miss entries and L2 -> L1 traffic of a
+        // W byte.  Measured at 8192^3 (TIMING-ONLY ablations, UMV_GEMM_TILE=966x): x pieces read as contiguous KiB 827 -> 766 us, no
+        // x pieces 712, no W pieces 663, no pieces at all 535 (2.05 PFLOP/s), pieces and fragment reads without MFMAs 722 us AT
+        // 2.4 GHz: the staging path, not the matrix pipe, sets the pace of this kernel.  (Issuing the two half-line pieces back
+        // to back in one step was tried first: 846 -> 941 us - the second request does not merge with the miss in flight.)
+        // Here a piece is 8 rows x 128 bytes = one k-step PAIR of 8 rows: lane L brings the 16-byte chunk (L & 7) ^ ((L >> 3) & 7) of
+        // row L >> 3, so that the row-major image [row][8 chunks] in LDS is XOR-swizzled by the row and the B fragment read of k-tile
+        // 2q + h, lane (r, g) -> chunk (4h + g) ^ (r & 7) of row r, is conflict free (each quarter-wave group covers all 64 banks).
+        // Rings: W 3 slots of one k-step (W(t+3) takes the slot of tile t, free behind the head barrier of body t), x 3 slots of one
+        // k-step pair (pair q is issued half in body 2q-5, half in body 2q-4): every wave issues WPW + XPB pieces per body, x first,
+        // so the counted wait at the head of a body - W(t+1) landed, the pieces of the previous body may fly - is one constant.
+        // Same MFMAs on the same operands in the same order: bit-identical to SCHED = 1.
+        constexpr int WPW = WTILES / NW, XPP = (BM / 8) / NW, XPB = XPP / 2, NP = WPW + XPB;
+        static_assert(KTS == 1 && WTILES % NW == 0 && (BM / 8) % NW == 0 && XPP % 2 == 0, "full-line x staging: even split of the pieces over the waves");
+        constexpr int WSLOT = WTILES * 1024, XSLOT = BM * 128, XBASE = 3 * WSLOT;
         constexpr int NRD = TN + TM, NMMA = TN * TM;
-        static_assert(NRD <= NMMA && 2 * XPW + WPW <= NMMA, "at most one read / piece per MFMA");
-        const bool ragged_k = (a.K & 31) != 0 && kt1 == KT;      // the last k-tile needs per-lane zero fill
-        // W: tile wave * WPW + i of the block; x: row-tile wave * XPW + i, two k-tiles (even, odd) per pair
+        static_assert(NRD <= NMMA && NP <= NMMA, "at most one read / piece per MFMA");
+        const int kx_rel = min(a.K, kt1 * 32) - kt0 * 32;             // valid k (elements) of this block's range, relative to kt0
         const bf16_t* curW[WPW];
         int bumpW[WPW];
-        const bf16_t* curX[XPW][2];
+        const bf16_t* curX[XPP];
+        const int xchunk = (lane & 7) ^ ((lane >> 3) & 7);
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int nt = nt_blk + wave * WPW + i;
@@ -1053,50 +1060,46 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
             bumpW[i] = ok ? 512 : 0;
         }
 #pragma unroll
-        for (int i = 0; i < XPW; ++i) {
-            const int m = m0 + (wave * XPW + i) * 16 + r;
+        for (int i = 0; i < XPP; ++i) {
+            const int m = m0 + (wave * XPP + i) * 8 + (lane >> 3);
             const int mm = m < a.M ? m : a.M - 1;                // rows past M are clamped (their outputs are masked)
             const int64_t row = a.row_idx ? (int64_t)a.row_idx[mm] : (int64_t)mm;
-            curX[i][0] = a.x + row * a.ldx + kt0 * 32 + g * 8;
-            curX[i][1] = curX[i][0] + 32;
+            curX[i] = a.x + row * a.ldx + kt0 * 32 + xchunk * 8;
         }
         // (char* and a cast at the call: a lambda RETURNING an address_space(3) pointer makes the host pass drop the kernel's stub
         // without a diagnostic - the library then fails to load with an undefined __device_stub__ symbol)
-        auto dstW = [&](int buf, int i) -> char* { return smem + buf * BUF + (wave * WPW + i) * 1024; };
-        auto dstX = [&](int buf, int i) -> char* { return smem + buf * BUF + (WTILES + wave * XPW + i) * 1024; };
-        // the W pieces of k-tile kt (relative to kt0) / the x pieces of k-tiles kt, kt + 1: pointers for this issue, then the bump.
-        // Tiles past the K range read the zero page (and keep the count of pieces in flight uniform); the last, partial k-tile
-        // selects per lane.
+        auto dstW = [&](int slot, int i) -> char* { return smem + slot * WSLOT + (wave * WPW + i) * 1024; };
+        auto dstX = [&](int slot, int i) -> char* { return smem + XBASE + slot * XSLOT + (wave * XPP + i) * 1024; };
         const bf16_t* pw[WPW];
-        const bf16_t* px[XPW][2];
-        auto prep_w = [&](int kt) {
+        const bf16_t* px[XPB];
+        auto prep_w = [&](int kt) {                 // the W pieces of k-tile kt (relative to kt0): zero page past the K range
 #pragma unroll
             for (int i = 0; i < WPW; ++i) {
                 pw[i] = kt < KTL ? curW[i] : zero;
                 curW[i] += bumpW[i];
             }
         };
-        auto prep_x = [&](int kt) {
+        auto prep_x = [&](int q, auto HALF) {       // pieces [HALF * XPB, +XPB) of k-step pair q: per-lane zero fill at the K tail
+            constexpr int hf = decltype(HALF)::value;
+            const int k0 = q * 64;
+            if (k0 + 64 <= kx_rel) {
 #pragma unroll
-            for (int i = 0; i < XPW; ++i)
+                for (int i = 0; i < XPB; ++i) { px[i] = curX[hf * XPB + i]; curX[hf * XPB + i] += 64; }
+            } else {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const bf16_t* p = curX[i][h];
-                    if (kt + h >= KTL) p = zero;
-                    else if (ragged_k && kt + h == KTL - 1) p = ((kt0 + kt + h) * 32 + g * 8 < a.K) ? p : zero;
-                    px[i][h] = p;
-                    curX[i][h] += 64;
-                }
+                for (int i = 0; i < XPB; ++i) { px[i] = (k0 + xchunk * 8 < kx_rel) ? curX[hf * XPB + i] : zero; curX[hf * XPB + i] += 64; }
+            }
         };
-        // prologue, in the order the loop would have issued them: W(0), x(0), x(1), W(1), x(2), x(3), W(2)
+        // prologue, in the order the loop would have issued it: x pair 0, W(0), x pair 1, W(1), first half of x pair 2, W(2)
 #pragma unroll
-        for (int t = 0; t <= 2; ++t) {
-            if (t != 1) {
-                prep_x(t);
+        for (int t = 0; t < 3; ++t) {
+            prep_x(t, std::integral_constant<int, 0>{});
 #pragma unroll
-                for (int i = 0; i < XPW; ++i)
+            for (int i = 0; i < XPB; ++i) __builtin_amdgcn_global_load_lds((const void*)px[i], (lds_ptr_t)dstX(t, i), 16, 0, 0);
+            if (t < 2) {
+                prep_x(t, std::integral_constant<int, 1>{});
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) __builtin_amdgcn_global_load_lds((const void*)px[i][h], (lds_ptr_t)dstX(t + h, i), 16, 0, 0);
+                for (int i = 0; i < XPB; ++i) __builtin_amdgcn_global_load_lds((const void*)px[i], (lds_ptr_t)dstX(t, XPB + i), 16, 0, 0);
             }
             prep_w(t);
 #pragma unroll
@@ -1104,7 +1107,9 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         }
         bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
         const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-        const uint32_t woff = wn * TN * 1024 + lane * 16, xoff = WTILES * 1024 + wm * TM * 1024 + lane * 16;
+        const uint32_t woff = wn * TN * 1024 + lane * 16;
+        // x fragment of k half h: row (wm * TM + j) * 16 + r, chunk (4h + g) ^ (r & 7)
+        const uint32_t xoff0 = XBASE + (wm * TM * 16 + r) * 128 + ((g ^ (r & 7)) << 4), xoff1 = xoff0 ^ 64;
         auto land = [&](bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
             for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
         };
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPW + 2 * XPW) : "memory");      // x(0), x(1), W(0) landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPP + XPB + 2 * WPW) : "memory");      // x pair 0 and W(0) landed; pair 1, W(1), half of pair 2 and W(2) may fly
         UMV_BARRIER();
         static_for<0, TN>([&](auto T) {
             constexpr int t = decltype(T)::value;
@@ -1120,34 +1125,34 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         });
         static_for<0, TM>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            lds_read_frag<j * 1024>(xfA[j], lds0 + xoff);
+            lds_read_frag<j * 2048>(xfA[j], lds0 + xoff0);
         });
         land(wfA, xfA);
         auto body = [&](auto EVEN, int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
             constexpr bool even = decltype(EVEN)::value;
-            constexpr int NP = even ? WPW : 2 * XPW + WPW;
             // the fragments of tile `step` are in registers; tile step + 1 must have landed before its reads below
-            if constexpr (even) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XPW + WPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-            UMV_BARRIER();                                   // ... everyone's; and the buffers of tiles step - 1 and step are free
-            if constexpr (!even) prep_x(step + 3);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            UMV_BARRIER();                                   // ... everyone's; and the slot of W tile `step` is free
+            const int q = (step + 5) >> 1;                   // the x pair this body stages half of
+            if constexpr (even) prep_x(q, std::integral_constant<int, 1>{});
+            else prep_x(q, std::integral_constant<int, 0>{});
             prep_w(step + 3);
-            const int bw = (step + 3) % NBUF, bx0 = (step + 3) % NBUF;
-            const uint32_t nb = lds0 + ((step + 1) % NBUF) * BUF;
-            const uint32_t wa = nb + woff, xa = nb + xoff;
+            const int sw = step % 3, sx = q % 3;
+            const uint32_t wa = lds0 + ((step + 1) % 3) * WSLOT + woff;
+            const uint32_t xa = lds0 + (((step + 1) >> 1) % 3) * XSLOT + (even ? xoff1 : xoff0);     // tile step + 1 is the odd half in an even body
             static_for<0, NMMA>([&](auto I) {
                 constexpr int i = decltype(I)::value, t = i / TM, j = i % TM;
                 mfma16_asm(acc[t][j], wc[t], xc[j]);
                 constexpr int rd = interleave_slot(i, NMMA, NRD);
                 if constexpr (rd >= 0 && rd < TN) lds_read_frag<(rd < TN ? rd : 0) * 1024>(wnx[rd < TN ? rd : 0], wa);
-                else if constexpr (rd >= TN) lds_read_frag<(rd >= TN ? rd - TN : 0) * 1024>(xnx[rd >= TN ? rd - TN : 0], xa);
+                else if constexpr (rd >= TN) lds_read_frag<(rd >= TN ? rd - TN : 0) * 2048>(xnx[rd >= TN ? rd - TN : 0], xa);
                 constexpr int pc = dma_slot(i, NMMA, NP);
                 if constexpr (pc >= 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (!even && pc < 2 * XPW)
-                        __builtin_amdgcn_global_load_lds((const void*)px[pc / 2][pc % 2], (lds_ptr_t)dstX((bx0 + pc % 2) % NBUF, pc / 2), 16, 0, 0);
+                    if constexpr (pc < XPB)
+                        __builtin_amdgcn_global_load_lds((const void*)px[pc < XPB ? pc : 0], (lds_ptr_t)dstX(sx, (even ? XPB : 0) + pc), 16, 0, 0);
                     else
-                        __builtin_amdgcn_global_load_lds((const void*)pw[even ? pc : pc - 2 * XPW], (lds_ptr_t)dstW(bw, even ? pc : pc - 2 * XPW), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const void*)pw[pc >= XPB ? pc - XPB : 0], (lds_ptr_t)dstW(sw, pc - XPB), 16, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -1196,7 +1201,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         e.flags = UMV_EPI_OUT_F32;
     }
     // bf16 outputs leave through LDS as whole rows (gemm_epilogue.h); fp32 outputs (split-K partials, OUT_F32) directly
-    constexpr bool LDS_EPI = BN * BM * 2 <= NBUF * BUF;
+    constexpr bool LDS_EPI = BN * BM * 2 <= STAGE_BYTES;
     if (LDS_EPI && !(e.flags & UMV_EPI_OUT_F32) && lds_epilogue_enabled) {
         UMV_BARRIER();      // every wave has read its last fragments: the staging buffers are free
         epi_wave_tile_lds<TN, TM, M32>(e, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, a.M, a.row_idx, nt_base, NTT,
@@ -1261,7 +1266,8 @@ template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int NT_ALL = BN / 16 * KTS + BM / 16 * KTS, NWV = WN * WM;
-    constexpr size_t lds = (size_t)NBUF * NT_ALL * 1024 + (BN * 2 + 15) / 16 * 16      // staging buffers + the tile's bias
+    constexpr size_t stage_bytes = (SCHED & 15) == 3 ? (size_t)3 * (BN / 16) * 1024 + (size_t)3 * BM * 128 : (size_t)NBUF * NT_ALL * 1024;
+    constexpr size_t lds = stage_bytes + (BN * 2 + 15) / 16 * 16                        // staging buffers + the tile's bias
                            + (size_t)((NT_ALL + NWV - 1) / NWV * NWV - NT_ALL) * 1024;   // + a spare KiB per surplus staging slot
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[UMV_MAX_DEVICES] = {};
@@ -1417,7 +1423,15 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
-    const int cfg = umv_gemm_tile_config(a.M, a.N, a.K);
+    int cfg = umv_gemm_tile_config(a.M, a.N, a.K);
+    {   // the staging variant of the interleaved tiles: full-line x staging (SCHED = 3) unless UMV_GEMM_XLINE=0 (A/B, tuning only).
+        // Bit-identical results; end to end on MI355X (tools/stage_profile.py, same box): text-to-image 1530 -> 1443 ms per batch of 4,
+        // prefill of 8 images 131.7 -> 130.7 ms, ViT tower 12.70 -> 12.50 ms.  (A 20-launch microbenchmark from a cold chip shows the
+        // opposite sign, -2..-8 %: the variant pays a longer prologue and wins only at the clocks a sustained load runs at.)
+        static int xline = -1;
+        if (xline < 0) { const char* e = getenv("UMV_GEMM_XLINE"); xline = (e && atoi(e) == 0) ? 0 : 1; }
+        if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : cfg;
+    }
     // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)
     if (cfg == 332) return launch_tiled<4, 1, 2, 2, 4, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 128, 3 buffers (120 KiB), 4 waves
     if (cfg == 333) return launch_tiled<4, 1, 2, 2, 2, 4>(a, KT, NTT, s);      // 128(n) x 32(m) x 64, 4 buffers (80 KiB)
@@ -1429,6 +1443,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
     if (cfg == 288) return launch_tiled<2, 4, 9, 2, 1, 4, 1>(a, KT, NTT, s);   // 288(n)x128(m)x32: N = 1152 / 4608 = 4 / 16 x 288 -> 256 tiles at 8192 / 2048 rows
     if (cfg == 266) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, MFMA / ds_read interleaved by hand
+#ifdef UMV_GEMM_ABLATIONS     // measured and not adopted / timing-only variants (UMV_GEMM_ABLATIONS=1 python -m unimedvl_amd.build)
     if (cfg == 9661) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 1>(a, KT, NTT, s);   // ablations of 266 (timing only)
     if (cfg == 9662) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 2>(a, KT, NTT, s);
     if (cfg == 9663) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 3>(a, KT, NTT, s);
@@ -1437,14 +1452,15 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 9666) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 6>(a, KT, NTT, s);
     if (cfg == 9667) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 7>(a, KT, NTT, s);
     if (cfg == 9668) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 8>(a, KT, NTT, s);
-    if (cfg == 366) return launch_tiled<2, 4, 8, 4, 1, 4, 3>(a, KT, NTT, s);   // 266 / 268 / 384 / 270 with the x pieces staged in pairs of k-steps (SCHED = 3)
-    if (cfg == 368) return launch_tiled<4, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
-    if (cfg == 484) return launch_tiled<4, 2, 6, 4, 1, 4, 3>(a, KT, NTT, s);
-    if (cfg == 370) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
     if (cfg == 566) return launch_tiled<2, 4, 8, 4, 1, 4, 2>(a, KT, NTT, s);   // the same tiles on v_mfma_f32_32x32x16_bf16 (SCHED = 2)
     if (cfg == 568) return launch_tiled<4, 2, 4, 4, 1, 4, 2>(a, KT, NTT, s);
     if (cfg == 684) return launch_tiled<4, 2, 6, 4, 1, 4, 2>(a, KT, NTT, s);
     if (cfg == 570) return launch_tiled<2, 2, 4, 4, 1, 4, 2>(a, KT, NTT, s);
+#endif
+    if (cfg == 366) return launch_tiled<2, 4, 8, 4, 1, 4, 3>(a, KT, NTT, s);   // 266 / 268 / 384 / 270 with the x operand staged in full 128-byte lines (SCHED = 3)
+    if (cfg == 368) return launch_tiled<4, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
+    if (cfg == 484) return launch_tiled<4, 2, 6, 4, 1, 4, 3>(a, KT, NTT, s);
+    if (cfg == 370) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
     if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
     if (cfg == 384) return launch_tiled<4, 2, 6, 4, 1, 4, 1>(a, KT, NTT, s);   // 384(n)x128(m)x32, 8 waves of 96 x 64: N = 1152 = 3 x 384 without padding
     if (cfg == 270) return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 128x128x32, 4 waves, 4 buffers (64 KiB, 2 WG/CU), interleaved

@@ -13,6 +13,77 @@ def patchify(image, patch_size):
     return image.permute(1, 3, 2, 4, 0).reshape(-1, p * p * c)
 
 
+class PackedVitImages:
+    """What `prepare_vit_images` puts under "packed_vit_tokens" when the engine patchifies on the device: the transformed
+    [3, H, W] images themselves.  The reference's tensor - torch.cat([patchify(im, p) ...]), data_utils.py:43-50 /
+    bagel.py:540-548 - is what `tokens()` returns, bit for bit; torch functions, attribute access and indexing on this object
+    all go through it, so code written against the reference's `generation_input` keeps working.  The engine never asks for
+    it: it uploads the images and runs umv_patchify_f32_bf16 (the host-side permute costs 4 ms per 448 x 448 image)."""
+
+    def __init__(self, images, patch_size):
+        self.images = [im.contiguous() for im in images]
+        self.patch_size = int(patch_size)
+        self._tokens = None
+
+    def tokens(self):
+        if self._tokens is None:
+            self._tokens = torch.cat([patchify(im.to(torch.float32).cpu() if im.is_cuda else im, self.patch_size) for im in self.images], dim=0)
+        return self._tokens
+
+    def token_counts(self):
+        p = self.patch_size
+        return [(im.shape[1] // p) * (im.shape[2] // p) for im in self.images]
+
+    @property
+    def shape(self):
+        return torch.Size((sum(self.token_counts()), self.patch_size ** 2 * (self.images[0].shape[0] if self.images else 3)))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def to(self, *args, **kwargs):
+        """device moves keep the images (dtype changes apply to the images as well)"""
+        out = PackedVitImages([im.to(*args, **kwargs) for im in self.images], self.patch_size)
+        return out
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        return self.tokens()[idx]
+
+    def __getattr__(self, name):          # anything else a tensor has: the reference's tensor answers
+        if name.startswith("_") or name in ("images", "patch_size"):
+            raise AttributeError(name)
+        return getattr(self.tokens(), name)
+
+    def __array__(self, *a, **k):
+        return self.tokens().numpy().__array__(*a, **k)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(v):
+            if isinstance(v, PackedVitImages):
+                return v.tokens()
+            if isinstance(v, (list, tuple)):
+                return type(v)(unwrap(u) for u in v)
+            return v
+        return func(*unwrap(tuple(args)), **{k: unwrap(v) for k, v in (kwargs or {}).items()})
+
+
+def _delegate(name):
+    def op(self, *a, **k):
+        return getattr(self.tokens(), name)(*a, **k)
+    op.__name__ = name
+    return op
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__neg__", "__matmul__",
+           "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__iter__", "__float__", "__int__", "__bool__"):
+    setattr(PackedVitImages, _n, _delegate(_n))
+PackedVitImages.__hash__ = object.__hash__
+
+
 def get_flattened_position_ids_extrapolate(img_h, img_w, patch_size, max_num_patches_per_side):
     """row * max_side + col (data_utils.py:53-58)."""
     nh, nw = img_h // patch_size, img_w // patch_size

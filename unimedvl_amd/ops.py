@@ -314,6 +314,20 @@ def cast_pad(x, Kp):
     return out
 
 
+def patchify(img, out, patch):
+    """Transformed image [C, H, W] fp32 (device) -> its patch tokens, cast to bf16 and zero padded, into out [(H/p)*(W/p), Kp]."""
+    lib = _lib.load()
+    _req(img, torch.float32, "img")
+    _req(out, BF16, "out")
+    if img.dim() != 3 or not img.is_contiguous() or out.dim() != 2 or out.stride(1) != 1:
+        raise _lib.UmvError("patchify: img must be a contiguous [C, H, W] tensor, out a [tokens, Kp] view with unit column stride")
+    C_, H, W = img.shape
+    if out.shape[0] != (H // patch) * (W // patch):
+        raise _lib.UmvError(f"patchify: out has {out.shape[0]} rows, the image has {(H // patch) * (W // patch)} patches")
+    check(lib.umv_patchify_f32_bf16(_p(img), C_, H, W, patch, _p(out), out.stride(0), out.shape[1], _stream()), "umv_patchify_f32_bf16")
+    return out
+
+
 class KVSlab:
     """One layer's K / V^T slabs: K [seg][nkv][cap][hd], V^T [seg][nkv][hd][cap]."""
 

@@ -9,7 +9,7 @@ position, text advances by its length.  Pure host code - usable without a GPU.
 import torch
 
 from .config import UniMedVLConfig
-from .data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
+from .data_utils import (PackedVitImages, get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
 
 
 class BagelPrep:
@@ -66,9 +66,13 @@ class BagelPrep:
             image_tensor = transforms(image)
             vit_pos.append(self.get_flattened_position_ids(image_tensor.size(1), image_tensor.size(2), self.vit_patch_size,
                                                            max_num_patches_per_side=self.vit_max_num_patch_per_side))
-            toks = patchify(image_tensor, self.vit_patch_size)
-            vit_tokens.append(toks)
-            n = toks.shape[0]
+            if getattr(self, "device_patchify", False):      # the engine patchifies on the device (PackedVitImages below)
+                vit_tokens.append(image_tensor)
+                n = (image_tensor.size(1) // self.vit_patch_size) * (image_tensor.size(2) // self.vit_patch_size)
+            else:
+                toks = patchify(image_tensor, self.vit_patch_size)
+                vit_tokens.append(toks)
+                n = toks.shape[0]
             vit_lens.append(n)
             vit_idx.extend(range(_curr, _curr + n))
             indexes.extend(range(curr, curr + n))
@@ -87,7 +91,10 @@ class BagelPrep:
             "packed_text_ids": torch.tensor(text_ids, dtype=torch.long),
             "packed_text_indexes": torch.tensor(text_idx, dtype=torch.long),
             "vit_token_seqlens": torch.tensor(vit_lens, dtype=torch.int),
-            "packed_vit_tokens": torch.cat(vit_tokens, dim=0),
+            # the reference's [sum tokens, 3 p^2] tensor, or - device_patchify - a stand-in that IS that tensor for whoever asks and
+            # hands the engine the images
+            "packed_vit_tokens": (PackedVitImages(vit_tokens, self.vit_patch_size) if getattr(self, "device_patchify", False)
+                                  else torch.cat(vit_tokens, dim=0)),
             "packed_vit_position_ids": torch.cat(vit_pos, dim=0),
             "packed_vit_token_indexes": torch.tensor(vit_idx, dtype=torch.long),
             "packed_position_ids": torch.tensor(pos_ids, dtype=torch.long),

@@ -10,6 +10,7 @@ import torch
 
 from . import ops
 from .config import UniMedVLConfig
+from .data_utils import PackedVitImages
 from .weights import ViTWeights
 
 BF16 = torch.bfloat16
@@ -29,20 +30,31 @@ class SiglipVisionModel:
         dev = self.device
         cu_host = [int(v) for v in cu_seqlens.tolist()]
         lens = [cu_host[i + 1] - cu_host[i] for i in range(len(cu_host) - 1)]
+        # PackedVitImages (prepare_vit_images with device_patchify): upload the [3, H, W] images, the tokens are made by
+        # umv_patchify_f32_bf16 inside forward(); a tensor: the reference's packed patch tokens
+        images = packed_pixel_values.images if isinstance(packed_pixel_values, PackedVitImages) else None
+        if images is not None and packed_pixel_values.token_counts() != lens:
+            raise ValueError(f"images of {packed_pixel_values.token_counts()} patches against vit_token_seqlens {lens}")
         if into is not None:
-            if into["lens"] != lens:
-                raise ValueError("a ViT plan can only be refreshed for the image sizes it was made for")
-            into["px"].copy_(packed_pixel_values.to(torch.float32), non_blocking=True)
+            if into["lens"] != lens or (images is None) != (into["imgs"] is None):
+                raise ValueError("a ViT plan can only be refreshed for the image sizes (and input kind) it was made for")
+            if images is None:
+                into["px"].copy_(packed_pixel_values.to(torch.float32), non_blocking=True)
+            else:
+                for dst, im in zip(into["imgs"], images):
+                    if dst.shape != im.shape:
+                        raise ValueError("a ViT plan can only be refreshed for the image sizes it was made for")
+                    dst.copy_(im.to(torch.float32), non_blocking=True)
             into["pos_ids"].copy_(packed_flattened_position_ids.to(torch.int64), non_blocking=True)
             return into
-        seg, slot = [], []
-        for i, n in enumerate(lens):
-            seg += [i] * n
-            slot += list(range(n))
-        return dict(px=packed_pixel_values.to(device=dev, dtype=torch.float32).contiguous(),
+        ln = torch.tensor(lens, dtype=torch.int64)
+        seg = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32), ln)
+        slot = (torch.arange(int(ln.sum()), dtype=torch.int64) - torch.repeat_interleave(torch.tensor(cu_host[:-1], dtype=torch.int64), ln)).to(torch.int32)
+        return dict(px=None if images is not None else packed_pixel_values.to(device=dev, dtype=torch.float32).contiguous(),
+                    imgs=None if images is None else [im.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous() for im in images],
                     pos_ids=packed_flattened_position_ids.to(device=dev, dtype=torch.int64),
                     cu_q=torch.tensor(cu_host, dtype=torch.int32).to(dev), kv_len=torch.tensor(lens, dtype=torch.int32).to(dev),
-                    meta=torch.tensor([seg, slot], dtype=torch.int32).to(dev), lens=lens, max_seqlen=int(max_seqlen))
+                    meta=torch.stack([seg, slot]).to(dev), lens=lens, max_seqlen=int(max_seqlen))
 
     @ops.on_device
     def forward(self, packed_pixel_values=None, packed_flattened_position_ids=None, cu_seqlens=None, max_seqlen=None, plan=None):
@@ -51,10 +63,17 @@ class SiglipVisionModel:
         if plan is None:
             plan = self.make_plan(packed_pixel_values, packed_flattened_position_ids, cu_seqlens, max_seqlen)
         px, pos_ids, cu_q, kv_len, meta, lens, max_seqlen = (plan[k] for k in ("px", "pos_ids", "cu_q", "kv_len", "meta", "lens", "max_seqlen"))
-        N = px.shape[0]
+        N = sum(lens)
         nimg = len(lens)
 
-        xb = ops.cast_pad(px, w.k_pad)                       # autocast's fp32->bf16 cast of the pixels
+        if plan.get("imgs") is not None:                     # patchify (data_utils.py:43-50) + the cast below, on the device
+            xb = torch.empty((N, w.k_pad), dtype=BF16, device=dev)
+            off = 0
+            for im, n in zip(plan["imgs"], lens):
+                ops.patchify(im, xb[off:off + n], cfg.patch)
+                off += n
+        else:
+            xb = ops.cast_pad(px, w.k_pad)                   # autocast's fp32->bf16 cast of the pixels
         h = ops.gemm(xb, w.patch)                            # patch embedding (siglip_navit.py:190)
         ops.add_rows(h, h, table=w.pos, idx=pos_ids)         # + position_embedding(ids) (:192)
         # no cache in this tower: q and K are read by the attention kernel where the QKV GEMM wrote them (column slices of
