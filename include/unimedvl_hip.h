@@ -259,10 +259,10 @@ int umv_decode_step_end(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, co
                         int64_t* pred_ids, int64_t* step_idx, int B, int max_len, umv_stream_t stream);
 /* umv_decode_step_end with the greedy pick folded in: ids[b] = column of the maximum key of argmax_partial[b][0..n_tiles)
  * (written by umv_gemm_bf16 / umv_gemm_fp8w with argmax_partial set), then the bookkeeping above.  `ids` is an OUTPUT here
- * (the token the next step embeds).  One workgroup per sample; `ticket` is one zero-initialised int32 owned by the caller
- * (the last workgroup to arrive advances step_idx and resets it). */
+ * (the token the next step embeds).  One workgroup per sample, and one step counter PER SAMPLE: step_idx has B entries (all
+ * equal; the caller zeroes them), workgroup b reads and advances step_idx[b] - no word is shared between workgroups. */
 int umv_decode_step_end_argmax(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const uint64_t* argmax_partial, int n_tiles,
-                               int64_t* ids, int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int32_t* ticket, int B,
+                               int64_t* ids, int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int B,
                                int max_len, umv_stream_t stream);
 
 

@@ -399,19 +399,18 @@ def test_gemm_argmax_epilogue(ops, M, N, K, fp8):
     ids = torch.full((B,), -1, dtype=torch.int64, device="cuda")
     in_ids = torch.zeros((max_len, B), dtype=torch.int64, device="cuda")
     pred = torch.zeros((max_len, B), dtype=torch.int64, device="cuda")
-    step = torch.tensor([2], dtype=torch.int64, device="cuda")
-    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ops.decode_step_end_argmax(slot, pos, kvl, part, ids, in_ids, pred, step, ticket)
+    step = torch.full((B,), 2, dtype=torch.int64, device="cuda")          # one counter per sample
+    ops.decode_step_end_argmax(slot, pos, kvl, part, ids, in_ids, pred, step)
     ref = torch.argmax(logits.float(), -1)
     assert torch.equal(ids, ref), (ids.tolist()[:8], ref.tolist()[:8])
     tie_rows = (logits[:, 7] == logits.float().max(-1).values.to(logits.dtype))
     assert torch.equal(ids[tie_rows], torch.full_like(ids[tie_rows], 7))
     assert torch.equal(pred[2], ref) and torch.equal(in_ids[3], ref) and int(pred[3].abs().sum()) == 0
-    assert int(step) == 3 and int(ticket) == 0
+    assert torch.equal(step, torch.full_like(step, 3))
     assert torch.equal(slot, torch.arange(B, **i32) + 1) and torch.equal(pos, torch.arange(B, **i32) + 101)
-    # a second step through the same buffers (the ticket was reset)
-    ops.decode_step_end_argmax(slot, pos, kvl, part, ids, in_ids, pred, step, ticket)
-    assert int(step) == 4 and torch.equal(pred[3], ref) and torch.equal(in_ids[4], ref)
+    # a second step through the same buffers
+    ops.decode_step_end_argmax(slot, pos, kvl, part, ids, in_ids, pred, step)
+    assert torch.equal(step, torch.full_like(step, 4)) and torch.equal(pred[3], ref) and torch.equal(in_ids[4], ref)
     with pytest.raises(Exception):
         ops.gemm(rnd((100, K), 92).cuda(), lin if not fp8 else ops.PackedLinear.from_weight(w.cuda()),
                  argmax_partial=torch.zeros((100, (N + 15) // 16), dtype=torch.int64, device="cuda"))

@@ -98,7 +98,7 @@ _SIGS = {
     "umv_decode_step_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_void_p]),
     "umv_decode_step_end_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                             C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_timestep_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "umv_cfg_renorm_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]),

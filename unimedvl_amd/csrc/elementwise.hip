@@ -695,6 +695,53 @@ __global__ __launch_bounds__(256) void qkv_split_tile_kernel(umv_qkv_post_args a
     }
 }
 
+// V-only split (the cache-less SigLIP tower: q and K are read by the attention kernel where the QKV GEMM wrote them) as an
+// in-register transpose: a thread owns 8 tokens x 8 dims - eight 16-byte loads (one per token), an 8 x 8 transpose of bf16
+// pairs with v_perm_b32, eight 16-byte stores (one per dim: 8 consecutive slots of a V^T row).  A wave is 8 dim-octets x 8
+// token-octets, so a load instruction covers 8 x 128 contiguous bytes of 8 token rows and a store instruction 8 x 128
+// contiguous bytes of 8 V^T rows: whole cache lines both ways (the LDS version above writes 16 bytes per V^T row and
+// workgroup: 19.6 us per ViT layer for 2 x 18.9 MB).  Token octets that are not 8 consecutive, 8-aligned slots of one
+// segment fall back to element stores.
+__global__ __launch_bounds__(256) void v_transpose_kernel(umv_qkv_post_args a) {
+    const int HD = a.hd, nheads = a.nq + 2 * a.nkv, nv = a.nkv * HD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 7, jl = lane >> 3;
+    const int e0 = (blockIdx.y * 8 + cl) * 8;                       // first of this thread's 8 V dims (over all kv heads)
+    const int t0 = ((int)blockIdx.x * 4 + wave) * 64 + jl * 8;      // first of its 8 tokens
+    if (e0 >= nv || t0 >= a.T) return;
+    const int nt = min(8, a.T - t0);
+    const bf16_t* src = a.qkv + (int64_t)t0 * nheads * HD + (int64_t)(a.nq + a.nkv) * HD + e0;
+    u32x4 r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = i < nt ? *reinterpret_cast<const u32x4*>(src + (int64_t)i * nheads * HD) : (u32x4){0u, 0u, 0u, 0u};
+    const int seg0 = a.tok_seg[t0], slot0 = a.tok_slot[t0];
+    bool run8 = nt == 8 && (slot0 & 7) == 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < nt) run8 = run8 && a.tok_seg[t0 + i] == seg0 && a.tok_slot[t0 + i] == slot0 + i;
+    const int h = e0 / HD, d0 = e0 - h * HD;                        // HD % 8 == 0: the 8 dims lie in one head
+    if (run8) {
+        bf16_t* dst = a.vt_slab + seg0 * a.v_seg_stride + h * a.v_head_stride + (int64_t)d0 * a.v_d_stride + slot0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            // bytes of {hi = r[2k+1], lo = r[2k]}.dword[d >> 1]: low halves 0x05040100, high halves 0x07060302
+            const uint32_t sel = (d & 1) ? 0x07060302u : 0x05040100u;
+            u32x4 o;
+            o.x = __builtin_amdgcn_perm(r[1][d >> 1], r[0][d >> 1], sel);
+            o.y = __builtin_amdgcn_perm(r[3][d >> 1], r[2][d >> 1], sel);
+            o.z = __builtin_amdgcn_perm(r[5][d >> 1], r[4][d >> 1], sel);
+            o.w = __builtin_amdgcn_perm(r[7][d >> 1], r[6][d >> 1], sel);
+            *reinterpret_cast<u32x4*>(dst + (int64_t)d * a.v_d_stride) = o;
+        }
+    } else {
+        for (int i = 0; i < nt; ++i) {
+            bf16_t* dst = a.vt_slab + a.tok_seg[t0 + i] * a.v_seg_stride + h * a.v_head_stride + (int64_t)d0 * a.v_d_stride + a.tok_slot[t0 + i];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) dst[(int64_t)d * a.v_d_stride] = (bf16_t)(r[i][d >> 1] >> ((d & 1) * 16));
+        }
+    }
+}
+
 extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap, UMV_ERR_ARG, "qkv_post: null args");
     const umv_qkv_post_args& a = *ap;
@@ -711,7 +758,10 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     dim3 grid((unsigned)((items + 3) / 4)), block(256);
     const size_t tile_lds = (size_t)8 * a.nkv * a.hd * sizeof(bf16_t);
     const bool tile_ok = (a.hd % 8) == 0 && tile_lds <= 64 * 1024;
-    if (!a.q_norm_w && tile_ok) {
+    if (v_only) {       // (hd % 8 == 0 checked above)
+        const int nv8 = a.nkv * a.hd / 8;
+        hipLaunchKernelGGL(v_transpose_kernel, dim3((unsigned)((a.T + 255) / 256), (unsigned)((nv8 + 7) / 8)), block, 0, (hipStream_t)stream, a);
+    } else if (!a.q_norm_w && tile_ok) {
         hipLaunchKernelGGL(qkv_split_tile_kernel, dim3((unsigned)((a.T + 7) / 8)), block, tile_lds, (hipStream_t)stream, a);
     } else if (!a.q_norm_w) {
         hipLaunchKernelGGL(qkv_split_kernel, grid, block, 0, (hipStream_t)stream, a);
@@ -764,20 +814,16 @@ extern "C" int umv_decode_step_end(int32_t* tok_slot, int32_t* tok_pos, int32_t*
 }
 
 // Greedy pick + end of step in one launch: one workgroup per sample takes the maximum of the per-tile keys the lm_head GEMM
-// epilogue left (gemm_epilogue.h::argmax_key), then does decode_step_end_kernel's bookkeeping for its sample.  Every
-// workgroup reads s = step_idx[0] BEFORE it takes a ticket and the last ticket holder writes s + 1, so no workgroup can see
-// the new value (relaxed device-scope atomics on one word; the kernel boundary publishes everything else).
+// epilogue left (gemm_epilogue.h::argmax_key), then does decode_step_end_kernel's bookkeeping for its sample.  The step counter
+// is PER SAMPLE - step_idx[b], all equal - so that no workgroup reads a word another workgroup of the same launch writes
+// (rounds 2-3 shared step_idx[0] behind a relaxed ticket; correct on this hardware, not by the memory model).
 __global__ __launch_bounds__(256) void decode_step_end_argmax_kernel(int32_t* slot, int32_t* pos, int32_t* kv_len,
                                                                      const uint64_t* __restrict__ part, int n_tiles, int64_t* ids,
                                                                      int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx,
-                                                                     int32_t* ticket, int B, int max_len) {
+                                                                     int B, int max_len) {
     __shared__ uint64_t sm[4];
     const int b = blockIdx.x;
-    // step_idx[0] is read by every workgroup and advanced by the LAST ticket holder: both sides use relaxed agent-scope atomics (no
-    // C++ data race), and the compiler barrier in front of the ticket keeps the read and the stores that depend on it ahead of the
-    // ticket in program order - a wave issues its memory operations in order, so no workgroup can see the advanced counter.
-    // (A release / acquire pair on the ticket would say the same formally and cost an L2 write-back + invalidate per step.)
-    const int64_t s = __hip_atomic_load(step_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t s = step_idx[b];
     const uint64_t* row = part + (int64_t)b * n_tiles;
     uint64_t best = 0;
     constexpr int UA = 8;      // all loads of a thread in flight together: one round trip for up to 2048 tiles per pass
@@ -805,22 +851,17 @@ __global__ __launch_bounds__(256) void decode_step_end_argmax_kernel(int32_t* sl
         if (s < max_len) pred_ids[s * B + b] = id;
         if (s + 1 < max_len) in_ids[(s + 1) * B + b] = id;
         slot[b] += 1; pos[b] += 1; kv_len[b] += 1;
-        asm volatile("" ::: "memory");
-        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == B - 1) {
-            __hip_atomic_store(step_idx, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        step_idx[b] = s + 1;
     }
 }
 extern "C" int umv_decode_step_end_argmax(int32_t* tok_slot, int32_t* tok_pos, int32_t* kv_len, const uint64_t* argmax_partial, int n_tiles,
-                                          int64_t* ids, int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int32_t* ticket, int B,
+                                          int64_t* ids, int64_t* in_ids, int64_t* pred_ids, int64_t* step_idx, int B,
                                           int max_len, umv_stream_t stream) {
-    UMV_CHECK(tok_slot && tok_pos && kv_len && argmax_partial && ids && in_ids && pred_ids && step_idx && ticket && max_len > 0 && n_tiles > 0,
+    UMV_CHECK(tok_slot && tok_pos && kv_len && argmax_partial && ids && in_ids && pred_ids && step_idx && max_len > 0 && n_tiles > 0,
               UMV_ERR_ARG, "decode_step_end_argmax: bad args");
     if (B == 0) return UMV_OK;
     hipLaunchKernelGGL(decode_step_end_argmax_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tok_slot, tok_pos, kv_len, argmax_partial,
-                       n_tiles, ids, in_ids, pred_ids, step_idx, ticket, B, max_len);
+                       n_tiles, ids, in_ids, pred_ids, step_idx, B, max_len);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }

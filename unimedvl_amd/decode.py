@@ -62,7 +62,9 @@ class DecodeSession:
         self.pred_ids = torch.zeros((max_length, B), dtype=torch.int64, device=dev)  # token predicted at each step
         if max_length > 0:
             self.in_ids[0].copy_(self.ids)
-        self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        # step counter(s): entry 0 is THE counter (sampling, the unfused step end); the fused argmax step end keeps one per sample
+        # so that its workgroups share no word (umv_decode_step_end_argmax)
+        self.step_idx = torch.zeros(max(B, 1), dtype=torch.int64, device=dev)
         max_kv = max(cache.lens) + max_length + 1
         # split the key range so that every wavefront walks ~2 blocks of 32 keys (latency bound otherwise)
         if nsplit is None and os.environ.get("UMV_DECODE_NSPLIT"):
@@ -88,7 +90,6 @@ class DecodeSession:
         self.fused_argmax = (not do_sample) and B <= 64 and os.environ.get("UMV_DECODE_FUSED_ARGMAX", "1") not in ("0", "")
         if self.fused_argmax:
             self.amax_part = torch.zeros((B, (cfg.vocab + 15) // 16), dtype=torch.int64, device=dev)
-            self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         w = llm.w
         # K splits of the QKV / o / down GEMMs: "q,o,d" (1 = that GEMM is not split), "0" = none, "auto" by batch / weights.
         # Measured on MI355X (bench.py --batch B, ms per step), no split -> 3,4,4:
@@ -176,7 +177,7 @@ class DecodeSession:
             ops.gemm(self.hn, w.lm_head, out=self.logits, argmax_partial=self.amax_part)
             # ids = argmax; pred_ids[step] = in_ids[step + 1] = ids; slot / position / kv_len / step += 1: one launch
             ops.decode_step_end_argmax(self.tok_slot, self.tok_pos, self.kv_len, self.amax_part, self.ids, self.in_ids, self.pred_ids,
-                                       self.step_idx, self.ticket)
+                                       self.step_idx)
             return
         ops.gemm(self.hn, w.lm_head, out=self.logits)
         if self.do_sample:

@@ -81,25 +81,25 @@ class Qwen2MoT:
         existing plan IN PLACE (same device addresses) - what a captured HIP graph of the forward reads at replay."""
         cfg, dev = self.cfg, self.device
         qlens = [int(q) for q in qlens]
-        # segment and cache slot of every query token (vectorised: 33k tokens for 32 images cost ~10 ms as Python lists)
-        ql = torch.tensor(qlens, dtype=torch.int64)
-        cu64 = torch.nn.functional.pad(torch.cumsum(ql, 0), (1, 0))
-        seg_t = torch.repeat_interleave(torch.arange(len(qlens), dtype=torch.int32), ql)
-        slot_t = (torch.arange(int(cu64[-1]), dtype=torch.int64)
-                  - torch.repeat_interleave(cu64[:-1] - torch.tensor([int(c) for c in cache_lens[:len(qlens)]], dtype=torch.int64), ql)).to(torch.int32)
+        seg, slot = [], []
+        for s, (c, q) in enumerate(zip(cache_lens, qlens)):
+            seg += [s] * q
+            slot += list(range(c, c + q))
         pos = position_ids.to(dtype=torch.int32).cpu() if isinstance(position_ids, torch.Tensor) else torch.tensor(position_ids, dtype=torch.int32)
         # the rotary tables hold cfg.max_position rows and the kernels index them unchecked
         pmax = int(pos.max()) if pos.numel() else 0
         pmin = int(pos.min()) if pos.numel() else 0
         if pmin < 0 or pmax >= cfg.max_position:
             raise ValueError(f"position ids must lie in [0, {cfg.max_position}) (max_position_embeddings); got [{pmin}, {pmax}]")
-        if pos.numel() != seg_t.numel():
+        if pos.numel() != len(seg):
             raise ValueError("position ids do not match the query lengths")
-        if len(cache_lens) != len(qlens):
-            raise ValueError(f"cache holds {len(cache_lens)} samples, call has {len(qlens)}")
+        cu = [0]
+        for q in qlens:
+            cu.append(cu[-1] + q)
         lens_after = [c + q for c, q in zip(cache_lens, qlens)]
-        T, nseg = int(seg_t.numel()), len(qlens)
-        host = torch.cat([seg_t, slot_t, pos.reshape(-1), cu64.to(torch.int32), torch.tensor(lens_after, dtype=torch.int32)])
+        T, nseg = len(seg), len(qlens)
+        host = torch.cat([torch.tensor(seg, dtype=torch.int32), torch.tensor(slot, dtype=torch.int32), pos.reshape(-1),
+                          torch.tensor(cu, dtype=torch.int32), torch.tensor(lens_after, dtype=torch.int32)])
         if into is None:
             buf = host.to(dev, non_blocking=True)
             p = ForwardPlan()

@@ -498,18 +498,20 @@ def decode_step_end(tok_slot, tok_pos, kv_len, ids, in_ids, pred_ids, step_idx):
                                   ids.numel(), in_ids.shape[0], _stream()), "umv_decode_step_end")
 
 
-def decode_step_end_argmax(tok_slot, tok_pos, kv_len, argmax_partial, ids, in_ids, pred_ids, step_idx, ticket):
-    """ids = argmax over the per-tile keys the lm_head GEMM left in argmax_partial, then decode_step_end's bookkeeping."""
+def decode_step_end_argmax(tok_slot, tok_pos, kv_len, argmax_partial, ids, in_ids, pred_ids, step_idx):
+    """ids = argmax over the per-tile keys the lm_head GEMM left in argmax_partial, then decode_step_end's bookkeeping.
+    step_idx: one counter per sample ([B] int64, all equal)."""
     lib = _lib.load()
     for t, name in ((argmax_partial, "argmax_partial"), (ids, "ids"), (in_ids, "in_ids"), (pred_ids, "pred_ids"), (step_idx, "step_idx")):
         _req(t, torch.int64, name)
-    _req(ticket, torch.int32, "ticket")
     B = ids.numel()
+    if step_idx.numel() < B:
+        raise _lib.UmvError(f"decode_step_end_argmax: step_idx holds {step_idx.numel()} counters for {B} samples")
     if not (in_ids.is_contiguous() and pred_ids.is_contiguous() and in_ids.shape == pred_ids.shape and in_ids.shape[1] == B
             and argmax_partial.is_contiguous() and argmax_partial.shape[0] == B):
         raise _lib.UmvError("decode_step_end_argmax: in_ids / pred_ids [max_len, B], argmax_partial [B, n_tiles], all contiguous")
     check(lib.umv_decode_step_end_argmax(_p(tok_slot), _p(tok_pos), _p(kv_len), _p(argmax_partial), argmax_partial.shape[1], _p(ids),
-                                         _p(in_ids), _p(pred_ids), _p(step_idx), _p(ticket), B, in_ids.shape[0], _stream()),
+                                         _p(in_ids), _p(pred_ids), _p(step_idx), B, in_ids.shape[0], _stream()),
           "umv_decode_step_end_argmax")
 
 

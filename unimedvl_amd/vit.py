@@ -47,14 +47,15 @@ class SiglipVisionModel:
                     dst.copy_(im.to(torch.float32), non_blocking=True)
             into["pos_ids"].copy_(packed_flattened_position_ids.to(torch.int64), non_blocking=True)
             return into
-        ln = torch.tensor(lens, dtype=torch.int64)
-        seg = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32), ln)
-        slot = (torch.arange(int(ln.sum()), dtype=torch.int64) - torch.repeat_interleave(torch.tensor(cu_host[:-1], dtype=torch.int64), ln)).to(torch.int32)
+        seg, slot = [], []
+        for i, n in enumerate(lens):
+            seg += [i] * n
+            slot += list(range(n))
         return dict(px=None if images is not None else packed_pixel_values.to(device=dev, dtype=torch.float32).contiguous(),
                     imgs=None if images is None else [im.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous() for im in images],
                     pos_ids=packed_flattened_position_ids.to(device=dev, dtype=torch.int64),
                     cu_q=torch.tensor(cu_host, dtype=torch.int32).to(dev), kv_len=torch.tensor(lens, dtype=torch.int32).to(dev),
-                    meta=torch.stack([seg, slot]).to(dev), lens=lens, max_seqlen=int(max_seqlen))
+                    meta=torch.tensor([seg, slot], dtype=torch.int32).to(dev), lens=lens, max_seqlen=int(max_seqlen))
 
     @ops.on_device
     def forward(self, packed_pixel_values=None, packed_flattened_position_ids=None, cu_seqlens=None, max_seqlen=None, plan=None):
