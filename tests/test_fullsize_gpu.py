@@ -187,8 +187,10 @@ def test_fused_argmax_equals_separate_argmax(full, monkeypatch):
         sess = DecodeSession(model.language_model, deepcopy(cache), start, torch.tensor(rope), 7, use_graph=True)
         assert sess.fused_argmax == (fused == "1")
         sess.step(6)
+        # (entry 0 is THE step counter; the fused step end keeps one per sample - all equal - so that its workgroups share no word)
+        assert torch.equal(sess.step_idx, torch.full_like(sess.step_idx, 6)) if fused == "1" else int(sess.step_idx[0]) == 6
         runs.append((sess.pred_ids.clone(), sess.in_ids.clone(), sess.logits.clone(), sess.tok_pos.clone(), sess.kv_len.clone(),
-                     sess.step_idx.clone(), sess.ids.clone()))
+                     sess.step_idx[:1].clone(), sess.ids.clone()))
     for x, y in zip(*runs):
         assert torch.equal(x, y)
     assert int(runs[0][5]) == 6

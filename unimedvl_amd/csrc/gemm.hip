@@ -125,13 +125,22 @@ extern "C" int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t*
 #define SK_WAVES 8
 #define SK_XMAX 16   // NORM: K <= 8*16*32 = 4096
 
-template <int MB, int NT, int U>
+template <int MB, int NT, int U, int XL = 0>
 struct SkBuf {
     bf16x8 w[U][NT];
     bf16x8 x[U][MB];
+    u32x4 xp[XL ? U / 2 : 1][XL == 1 ? 1 : (XL ? 2 * MB : 1)];     // XL: the x pieces of the chunk's k-tile pairs on their way to LDS
 };
 
-template <int MB, int NT, int U, bool DB, int NORM>   // NORM: 0 = off, 8 / 16 = fused RMSNorm keeping that many x rows
+// XL (round 4): x reaches the MFMAs in FULL 128-byte lines.  The plain kernel loads x in fragment shape - per wave instruction
+// 16 rows x 64 bytes, half a line per row - and every workgroup re-reads all of x through L2 -> L1 (at 8 rows that is half the
+// weight bytes, at 32 rows twice them).  Here a wave loads 8 rows x 128 bytes per instruction (a k-tile PAIR of 8 rows, lane L:
+// row L >> 3, chunk (L & 7) ^ (L >> 3)), parks the piece in its own KiB of LDS (lane-linear ds_write_b128: the image is row-major,
+// XOR-swizzled by the row) and reads the B fragments of the two k-tiles back conflict free (lane (r, g), k half h: chunk
+// (4h + g) ^ (r & 7) of row r) - the tiled kernel's full-line staging (SCHED = 3) without the DMA.  Same operands, same MFMAs,
+// same order: bit-identical to the plain kernel.  XL = 2: two pieces per 16-row tile; XL = 1 (M <= 8): one piece, rows 8..15 of a
+// fragment re-read rows 0..7 (their output columns are never stored).  Needs an even U.
+template <int MB, int NT, int U, bool DB, int NORM, int XL = 0>   // NORM: 0 = off, 8 / 16 = fused RMSNorm keeping that many x rows
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_args a, int KT, int NTT) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [SK_WAVES][NT*MB*4][64] (+ norm partials)
     const int tid = threadIdx.x;
@@ -161,7 +170,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
     const int kt_per = (max(0, ks1 - ks0) + SK_WAVES - 1) / SK_WAVES;
     const int kt_begin = ks0 + wave * kt_per;
     const int kt_end = min(ks1, kt_begin + kt_per);
-    const int nk = max(0, kt_end - kt_begin);
+    // XL works on whole k-tile PAIRS (one 128-byte line of x per row): a slice that starts on an odd k-tile starts one tile early
+    // with that tile's weights masked to zero - an MFMA that adds exact zeros (the x it multiplies is the neighbour wave's, finite)
+    const int kt_lo = XL != 0 ? (kt_begin & ~1) : kt_begin;
+    const int nk = max(0, kt_end - kt_lo);
     const int nchunks = (nk + U - 1) / U;
     // TH = rows per n-tile of the packed image (16 standard; < 16 for the exact-partition decode copies,
     // whose lanes r >= TH carry no row): tile (nt, kt) holds [g][r < TH][8] = 4*TH*8 elements
@@ -174,23 +186,68 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
         const bool tv = (nt0 + t) < NTT;
         wbase[t] = a.wp + ((int64_t)(tv ? nt0 + t : 0) * KT) * tile_elems + (g * TH + (rowlane ? r : 0)) * 8;
     }
-    auto load_chunk = [&](int c, SkBuf<MB, NT, U>& b) {
+    static_assert(!XL || (U % 2 == 0 && NORM == 0), "full-line x staging: whole k-tile pairs per chunk, no fused norm");
+    static_assert(XL != 1 || MB == 1, "one-piece staging serves one 16-row tile of at most 8 valid rows");
+    constexpr int XLP = XL == 1 ? 1 : 2 * MB;          // pieces per k-tile pair
+    // XL: this lane's row of each 8-row piece and its 16-byte chunk of the pair's 128 bytes
+    const int xchunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const bf16_t* xprow[XL ? XLP : 1];
+    bool xpvalid[XL ? XLP : 1];
+    if constexpr (XL != 0) {
+#pragma unroll
+        for (int q = 0; q < XLP; ++q) {
+            const int m = q * 8 + (lane >> 3);
+            xpvalid[q] = m < a.M;
+            const int64_t row = xpvalid[q] ? (a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m) : 0;
+            xprow[q] = a.x + row * a.ldx + xchunk * 8;
+        }
+    }
+    char* xstage = reinterpret_cast<char*>(red) + wave * (U / 2 * XLP * 1024);      // XL: this wave's own staging KiBs
+    auto load_chunk = [&](int c, SkBuf<MB, NT, U, XL>& b) {
+        if constexpr (XL != 0) {
+#pragma unroll
+            for (int pr = 0; pr < U / 2; ++pr) {
+                const int kt = kt_lo + c * U + 2 * pr;
+                const int k = kt * 32 + xchunk * 8;
+#pragma unroll
+                for (int q = 0; q < XLP; ++q)
+                    b.xp[pr][q] = (kt < kt_end && xpvalid[q] && k < a.K) ? *reinterpret_cast<const u32x4*>(xprow[q] + (int64_t)kt * 32)
+                                                                         : (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kt = kt_begin + c * U + u;
-            const bool ok = kt < kt_end;
+            const int kt = kt_lo + c * U + u;
+            const bool ok = kt >= kt_begin && kt < kt_end;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 b.w[u][t] = (ok && rowlane) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wbase[t] + (int64_t)kt * tile_elems))
                                             : zero_frag();
-            if (!NORM) {
+            if (!NORM && XL == 0) {
                 const int k = kt * 32 + g * 8;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) b.x[u][mb] = (ok && xvalid[mb] && k < a.K) ? ldg_frag(xrow[mb] + k) : zero_frag();
             }
         }
     };
-    SkBuf<MB, NT, U> b0, b1;
+    // XL: the chunk's pieces go through the wave's LDS KiBs and come back as the B fragments the MFMAs take (LDS operations of
+    // one wave execute in order and nobody else touches these bytes: no barrier)
+    auto unstage = [&](SkBuf<MB, NT, U, XL>& b) {
+        if constexpr (XL != 0) {
+#pragma unroll
+            for (int pr = 0; pr < U / 2; ++pr)
+#pragma unroll
+                for (int q = 0; q < XLP; ++q) *reinterpret_cast<u32x4*>(xstage + (pr * XLP + q) * 1024 + lane * 16) = b.xp[pr][q];
+            const int rr = XL == 1 ? (r & 7) : r;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    b.x[u][mb] = *reinterpret_cast<const bf16x8*>(xstage + (u >> 1) * (XLP * 1024) + (mb * 16 + rr) * 128 +
+                                                                  ((((u & 1) * 4 + g) ^ (rr & 7)) << 4));
+        }
+    };
+    SkBuf<MB, NT, U, XL> b0, b1;
     if (nchunks > 0) load_chunk(0, b0);
 
     if constexpr (NORM != 0) {
@@ -286,6 +343,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
     } else {
         for (int c = 0; c < nchunks; c += 2) {
             if (DB && c + 1 < nchunks) load_chunk(c + 1, b1);
+            unstage(b0);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -295,6 +353,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
             if (c + 1 < nchunks) {
                 if (!DB) load_chunk(c + 1, b1);
                 if (c + 2 < nchunks && DB) load_chunk(c + 2, b0);
+                unstage(b1);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -306,6 +365,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
         }
     }
     // cross-wave reduction through LDS
+    if constexpr (XL != 0) __syncthreads();      // the reduction buffer overlays the waves' x staging KiBs: everyone has left the main loop
     constexpr int E4 = NT * MB;  // f32x4 fragments per lane
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -477,15 +537,19 @@ extern "C" int umv_quantize_pack_weight_fp8(const uint16_t* w, const uint16_t* w
     return UMV_OK;
 }
 
-template <int MB, int NT, int U>
+template <int MB, int NT, int U, int XL = 0>
 struct SkBuf8 {
     u32x4 w[U][NT];
     bf16x8 x[U][2][MB];
+    u32x4 xp[XL ? U : 1][XL == 1 ? 1 : (XL ? 2 * MB : 1)];      // XL: the 8-row x 128-byte x pieces of the chunk's k super-tiles
 };
 
 // Same work decomposition as gemm_skinny_kernel (8 waves split K in contiguous slices, LDS reduce in wave
 // order), over 64-wide k super-tiles; for K % 512 == 0 the slices - and so the fp32 sums - are identical.
-template <int MB, int NT, int U>
+// XL = full-line x staging as in gemm_skinny_kernel (a 64-wide k super-tile is exactly one 128-byte line per row): 1 = M <= 8,
+// one piece per super-tile (rows 8..15 of the fragment re-read rows 0..7: their output columns are never stored), 2 = two pieces
+// per 16-row tile.
+template <int MB, int NT, int U, int XL = 0>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_args a, int KT8, int NTT) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x;
@@ -529,7 +593,22 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
     // x costs as much L2->L1 traffic as the e4m3 weights at NT = 1 (M = 8 rows x 2 B vs 16 rows x 1 B per k) and is what
     // holds this kernel below the HBM rate: down_proj 18.2 us with these x loads, 12.8 us with x from a constant
     // (tools/skinny_bench.py; rotating the K order per workgroup or pre-packing x in fragment order did not help).
-    auto load_chunk = [&](int c, SkBuf8<MB, NT, U>& b) {
+    static_assert(XL != 1 || MB == 1, "one-piece staging serves one 16-row tile of at most 8 valid rows");
+    constexpr int XLP = XL == 1 ? 1 : 2 * MB;        // pieces per k super-tile
+    const int xchunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const bf16_t* xprow[XL ? XLP : 1];
+    bool xpvalid[XL ? XLP : 1];
+    if constexpr (XL != 0) {
+#pragma unroll
+        for (int q = 0; q < XLP; ++q) {
+            const int m = q * 8 + (lane >> 3);
+            xpvalid[q] = m < a.M;
+            const int64_t row = xpvalid[q] ? (a.row_idx ? (int64_t)a.row_idx[m] : (int64_t)m) : 0;
+            xprow[q] = a.x + row * a.ldx + xchunk * 8;
+        }
+    }
+    char* xstage = reinterpret_cast<char*>(red) + wave * (U * XLP * 1024);
+    auto load_chunk = [&](int c, SkBuf8<MB, NT, U, XL>& b) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kt = kt_begin + c * U + u;
@@ -537,6 +616,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 b.w[u][t] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase[t] + (int64_t)kt * 1024)) : (u32x4){0u, 0u, 0u, 0u};
+            if constexpr (XL != 0) {
+                const int k = kt * 64 + xchunk * 8;
+#pragma unroll
+                for (int q = 0; q < XLP; ++q)
+                    b.xp[u][q] = (ok && xpvalid[q] && k < a.K) ? *reinterpret_cast<const u32x4*>(xprow[q] + (int64_t)kt * 64) : (u32x4){0u, 0u, 0u, 0u};
+            } else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = kt * 64 + h * 32 + g * 8;
@@ -545,7 +630,21 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
             }
         }
     };
-    auto consume = [&](SkBuf8<MB, NT, U>& b) {
+    auto consume = [&](SkBuf8<MB, NT, U, XL>& b) {
+        if constexpr (XL != 0) {       // pieces -> the wave's own LDS KiBs (row-major, XOR-swizzled by the row) -> B fragments
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < XLP; ++q) *reinterpret_cast<u32x4*>(xstage + (u * XLP + q) * 1024 + lane * 16) = b.xp[u][q];
+            const int rr = XL == 1 ? (r & 7) : r;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        b.x[u][h][mb] = *reinterpret_cast<const bf16x8*>(xstage + u * (XLP * 1024) + (mb * 16 + rr) * 128 + (((h * 4 + g) ^ (rr & 7)) << 4));
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             bf16x8 wlo[NT], whi[NT];
@@ -561,7 +660,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
                 for (int mb = 0; mb < MB; ++mb) acc[t][mb] = mfma16(whi[t], b.x[u][1][mb], acc[t][mb]);
         }
     };
-    SkBuf8<MB, NT, U> b0, b1;
+    SkBuf8<MB, NT, U, XL> b0, b1;
     if (nchunks > 0) load_chunk(0, b0);
     for (int c = 0; c < nchunks; c += 2) {
         if (c + 1 < nchunks) load_chunk(c + 1, b1);
@@ -572,6 +671,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
         }
     }
     // cross-wave reduction + epilogue: identical to gemm_skinny_kernel (16-row tiles)
+    if constexpr (XL != 0) __syncthreads();      // the reduction buffer overlays the waves' x staging KiBs
     constexpr int E4 = NT * MB;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -625,14 +725,40 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
     }
 }
 
-template <int MB, int NT, int U>
-static int launch_skinny8(const umv_gemm_args& a, int KT8, int NTT, hipStream_t s) {
+static int skinny8_xl() {     // UMV_SKINNY8_XL: 0 never, 1 above 8 rows, 2 always (default; A/B only)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UMV_SKINNY8_XL"); v = e ? atoi(e) : 2; }
+    return v;
+}
+
+template <int MB, int NT, int U, int XL>
+static int launch_skinny8_v(const umv_gemm_args& a, int KT8, int NTT, hipStream_t s) {
     int blocks = (NTT + NT - 1) / NT;
     size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny8_kernel<MB, NT, U>), dim3(blocks, a.k_splits > 1 ? a.k_splits : 1), dim3(SK_WAVES * 64), lds, s, a,
+    if (XL != 0) {
+        const size_t xl = (size_t)SK_WAVES * U * (XL == 1 ? 1 : 2 * MB) * 1024;
+        if (xl > lds) lds = xl;
+        static bool attr_set[UMV_MAX_DEVICES] = {};
+        if (lds > 64 * 1024 && umv_first_on_device(attr_set))
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny8_kernel<MB, NT, U, XL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL((gemm_skinny8_kernel<MB, NT, U, XL>), dim3(blocks, a.k_splits > 1 ? a.k_splits : 1), dim3(SK_WAVES * 64), lds, s, a,
                        KT8, NTT);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
+}
+
+template <int MB, int NT, int U>
+static int launch_skinny8(const umv_gemm_args& a, int KT8, int NTT, hipStream_t s) {
+    const bool lines = (a.ldx % 64) == 0 && ((uintptr_t)a.x % 128) == 0;      // rows start on a 128-byte boundary
+    const int mode = skinny8_xl();
+    if (lines && mode && (mode > 1 || a.M > 8)) {
+        if constexpr (MB == 1) {
+            if (a.M <= 8) return launch_skinny8_v<MB, NT, U, 1>(a, KT8, NTT, s);
+        }
+        return launch_skinny8_v<MB, NT, U, 2>(a, KT8, NTT, s);
+    }
+    return launch_skinny8_v<MB, NT, U, 0>(a, KT8, NTT, s);
 }
 
 extern "C" int umv_gemm_fp8w(const umv_gemm_args* ap, umv_stream_t stream) {
@@ -1042,8 +1168,11 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         // k-step pair (pair q is issued half in body 2q-5, half in body 2q-4): every wave issues WPW + XPB pieces per body, x first,
         // so the counted wait at the head of a body - W(t+1) landed, the pieces of the previous body may fly - is one constant.
         // Same MFMAs on the same operands in the same order: bit-identical to SCHED = 1.
-        constexpr int WPW = WTILES / NW, XPP = (BM / 8) / NW, XPB = XPP / 2, NP = WPW + XPB;
-        static_assert(KTS == 1 && WTILES % NW == 0 && (BM / 8) % NW == 0 && XPP % 2 == 0, "full-line x staging: even split of the pieces over the waves");
+        // (W tiles that do not divide evenly over the waves - 288 columns: 18 - round WPW up; the surplus slots copy the zero page
+        // into a spare KiB each behind the bias so that every wave issues the same number of pieces)
+        constexpr int WPW = (WTILES + NW - 1) / NW, XPP = (BM / 8) / NW, XPB = XPP / 2, NP = WPW + XPB;
+        constexpr int WDUMP = STAGE_BYTES + (BN * 2 + 15) / 16 * 16;
+        static_assert(KTS == 1 && (BM / 8) % NW == 0 && XPP % 2 == 0, "full-line x staging: even split of the x pieces over the waves");
         constexpr int WSLOT = WTILES * 1024, XSLOT = BM * 128, XBASE = 3 * WSLOT;
         constexpr int NRD = TN + TM, NMMA = TN * TM;
         static_assert(NRD <= NMMA && NP <= NMMA, "at most one read / piece per MFMA");
@@ -1055,7 +1184,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int nt = nt_blk + wave * WPW + i;
-            const bool ok = nt < NTT;
+            const bool ok = nt < NTT && wave * WPW + i < WTILES;
             curW[i] = ok ? a.wp + ((int64_t)nt * KT + kt0) * 512 + lane * 8 : zero;
             bumpW[i] = ok ? 512 : 0;
         }
@@ -1068,7 +1197,10 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
         }
         // (char* and a cast at the call: a lambda RETURNING an address_space(3) pointer makes the host pass drop the kernel's stub
         // without a diagnostic - the library then fails to load with an undefined __device_stub__ symbol)
-        auto dstW = [&](int slot, int i) -> char* { return smem + slot * WSLOT + (wave * WPW + i) * 1024; };
+        auto dstW = [&](int slot, int i) -> char* {
+            const int f = wave * WPW + i;
+            return (WTILES % NW == 0 || f < WTILES) ? smem + slot * WSLOT + f * 1024 : smem + WDUMP + (f - WTILES) * 1024;
+        };
         auto dstX = [&](int slot, int i) -> char* { return smem + XBASE + slot * XSLOT + (wave * XPP + i) * 1024; };
         const bf16_t* pw[WPW];
         const bf16_t* px[XPB];
@@ -1267,8 +1399,9 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int NT_ALL = BN / 16 * KTS + BM / 16 * KTS, NWV = WN * WM;
     constexpr size_t stage_bytes = (SCHED & 15) == 3 ? (size_t)3 * (BN / 16) * 1024 + (size_t)3 * BM * 128 : (size_t)NBUF * NT_ALL * 1024;
+    constexpr size_t ndummy = (SCHED & 15) == 3 ? (size_t)((BN / 16 + NWV - 1) / NWV * NWV - BN / 16) : (size_t)((NT_ALL + NWV - 1) / NWV * NWV - NT_ALL);
     constexpr size_t lds = stage_bytes + (BN * 2 + 15) / 16 * 16                        // staging buffers + the tile's bias
-                           + (size_t)((NT_ALL + NWV - 1) / NWV * NWV - NT_ALL) * 1024;   // + a spare KiB per surplus staging slot
+                           + ndummy * 1024;                                            // + a spare KiB per surplus staging slot
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[UMV_MAX_DEVICES] = {};
     if (umv_first_on_device(attr_set)) {
@@ -1294,12 +1427,48 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     return UMV_OK;
 }
 
+// full-line x staging of the weight-streaming kernels: 1 (default) = above 8 rows, 2 = always, 0 = never (UMV_SKINNY_XL, A/B only).
+// Measured on MI355X (tools/skinny_bench.py, us, plain -> XL; profiles/r04_skinny_xl.txt): 32 rows qkv 21.3 -> 16.4, o 13.0 -> 9.9,
+// gate/up 59.3 -> 53.3, down 51.0 -> 34.8 (configs[3] decode step 4.445 -> 4.099 ms, 7199 -> 7807 tokens/s); 16 rows 14.3 -> 11.9 /
+// 9.0 -> 8.1 / 48.5 -> 47.2 / 33.5 -> 27.9; at 8 rows x is half the weight bytes and the 17 extra VGPRs cost gate/up its second
+// resident workgroup (125 -> 142 registers: 42.4 -> 45.4 us, step 3.167 -> 3.253 ms), so 8 rows and fewer keep the plain loads.
+static int skinny_xl() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UMV_SKINNY_XL"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 template <int MB, int NT, int U, bool DB, int NORM>
 static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) {
     int blocks = (NTT + NT - 1) / NT;
     size_t lds = (size_t)SK_WAVES * NT * MB * 4 * 64 * sizeof(float);
     if (NORM) lds += SK_WAVES * 16 * sizeof(float) + (size_t)KT * 4 * NORM * 16;
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM>), dim3(blocks, a.k_splits > 1 ? a.k_splits : 1), dim3(SK_WAVES * 64), lds, s,
+    const int nsplit = a.k_splits > 1 ? a.k_splits : 1;
+    if constexpr (NORM == 0 && U % 2 == 0) {
+        // (rows that start on a 128-byte boundary, so that a k-tile pair is one cache line; any K, any split)
+        if ((skinny_xl() > 1 || (skinny_xl() == 1 && a.M > 8)) && (a.ldx % 64) == 0 && ((uintptr_t)a.x % 128) == 0) {
+            auto go = [&](auto XLV) {
+                constexpr int XL = decltype(XLV)::value;
+                size_t l2 = lds;
+                const size_t xl = (size_t)SK_WAVES * (U / 2) * (XL == 1 ? 1 : 2 * MB) * 1024;
+                if (xl > l2) l2 = xl;
+                static bool attr_set[UMV_MAX_DEVICES] = {};
+                if (l2 > 64 * 1024 && umv_first_on_device(attr_set))
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MB, NT, U, DB, NORM, XL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM, XL>), dim3(blocks, nsplit), dim3(SK_WAVES * 64), l2, s, a, KT, NTT);
+            };
+            if constexpr (MB == 1) {
+                if (a.M <= 8) go(std::integral_constant<int, 1>{});
+                else go(std::integral_constant<int, 2>{});
+            } else {
+                go(std::integral_constant<int, 2>{});
+            }
+            UMV_LAUNCH_CHECK();
+            return UMV_OK;
+        }
+    }
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, NT, U, DB, NORM>), dim3(blocks, nsplit), dim3(SK_WAVES * 64), lds, s,
                        a, KT, NTT);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
@@ -1429,8 +1598,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // prefill of 8 images 131.7 -> 130.7 ms, ViT tower 12.70 -> 12.50 ms.  (A 20-launch microbenchmark from a cold chip shows the
         // opposite sign, -2..-8 %: the variant pays a longer prologue and wins only at the clocks a sustained load runs at.)
         static int xline = -1;
-        if (xline < 0) { const char* e = getenv("UMV_GEMM_XLINE"); xline = (e && atoi(e) == 0) ? 0 : 1; }
-        if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : cfg;
+        if (xline < 0) { const char* e = getenv("UMV_GEMM_XLINE"); xline = e ? atoi(e) : 1; }      // (2: also the 288-column tile, under evaluation)
+        if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : (cfg == 288 && xline > 1) ? 388 : cfg;
     }
     // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)
     if (cfg == 332) return launch_tiled<4, 1, 2, 2, 4, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 128, 3 buffers (120 KiB), 4 waves
@@ -1461,6 +1630,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 368) return launch_tiled<4, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
     if (cfg == 484) return launch_tiled<4, 2, 6, 4, 1, 4, 3>(a, KT, NTT, s);
     if (cfg == 370) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
+    if (cfg == 388) return launch_tiled<2, 4, 9, 2, 1, 4, 3>(a, KT, NTT, s);   // 288(n) x 128(m) with full-line x staging (18 W tiles on 8 waves: 3 slots each, 6 of them idle)
     if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
     if (cfg == 384) return launch_tiled<4, 2, 6, 4, 1, 4, 1>(a, KT, NTT, s);   // 384(n)x128(m)x32, 8 waves of 96 x 64: N = 1152 = 3 x 384 without padding
     if (cfg == 270) return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 128x128x32, 4 waves, 4 buffers (64 KiB, 2 WG/CU), interleaved
