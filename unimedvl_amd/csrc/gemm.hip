@@ -1427,14 +1427,15 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     return UMV_OK;
 }
 
-// full-line x staging of the weight-streaming kernels: 1 (default) = above 8 rows, 2 = always, 0 = never (UMV_SKINNY_XL, A/B only).
+// full-line x staging of the weight-streaming kernels: 2 (default) = always, 1 = above 8 rows only, 0 = never (UMV_SKINNY_XL, A/B only).
 // Measured on MI355X (tools/skinny_bench.py, us, plain -> XL; profiles/r04_skinny_xl.txt): 32 rows qkv 21.3 -> 16.4, o 13.0 -> 9.9,
 // gate/up 59.3 -> 53.3, down 51.0 -> 34.8 (configs[3] decode step 4.445 -> 4.099 ms, 7199 -> 7807 tokens/s); 16 rows 14.3 -> 11.9 /
-// 9.0 -> 8.1 / 48.5 -> 47.2 / 33.5 -> 27.9; at 8 rows x is half the weight bytes and the 17 extra VGPRs cost gate/up its second
-// resident workgroup (125 -> 142 registers: 42.4 -> 45.4 us, step 3.167 -> 3.253 ms), so 8 rows and fewer keep the plain loads.
+// 9.0 -> 8.1 / 48.5 -> 47.2 / 33.5 -> 27.9.  At 8 rows the two-piece form costs gate/up its second resident workgroup (125 -> 142
+// registers: 42.4 -> 45.4 us), the ONE-piece form (rows 0..7 only, 124 registers) wins: gate/up 42.5 -> 41.4 (6.57 TB/s), down
+// 26.0 -> 24.7, qkv 11.4 -> 9.2, headline step 3.161 -> 3.111 ms.
 static int skinny_xl() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("UMV_SKINNY_XL"); v = e ? atoi(e) : 1; }
+    if (v < 0) { const char* e = getenv("UMV_SKINNY_XL"); v = e ? atoi(e) : 2; }
     return v;
 }
 
