@@ -10,3 +10,7 @@ for SH in 2048,4608,3584 2048,3584,3584 2048,3584,18944 2048,37888,3584,1 8208,4
   SHAPE=$SH SECONDS=2 UMV_GEMM_TILE=288 UMV_GEMM_XLINE=1 timeout 120 python tools/gemm_power.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/tile=  288/tile=288old/' | tee -a $O/sweep.txt
   SHAPE=$SH SECONDS=2 timeout 120 python tools/gemm_power.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/sweep.txt
 done
+for SK in "3,4,4" "1,4,4" "1,1,4" "3,1,4" "2,2,4" "3,4,8" "1,2,4"; do
+  echo "== SPLITK=$SK" | tee -a $O/splitk.txt
+  UMV_DECODE_SPLITK=$SK timeout 600 python bench.py --no-cpu-baseline --no-t2i --no-vit --no-load-path --no-fp8 --no-report 2>&1 | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" | tee -a $O/splitk.txt
+done

@@ -742,6 +742,72 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(umv_qkv_post_args a) {
     }
 }
 
+// q / k heads of a LONG forward (prefill, flow passes: T >= 64 rows of bf16 qkv, head_dim 128): qkv_post_kernel's arithmetic with
+// 8-byte accesses - 16 lanes per (token, head), lane `sub` owns elements 4 sub .. 4 sub + 3 of the first half and the matching
+// ones of the second half (rotate_half pairs x[d] with x[d + 64]), four items per wave.  The per-(token, head) wave with 2-byte
+// accesses took 25-27 us per layer of a guided flow pass (2064 rows) and 100 us per layer of an 8-image prefill.  The row sum of
+// squares follows qkv_post_kernel's butterfly exactly (lane bits 5, 4, 3, 2 there are sub bits 3, 2, 1, 0 here, lane bits 1, 0
+// the element index), so the results are bit-identical and a decode step still equals the prefill of the same token.
+// V heads go through v_transpose_kernel.
+__global__ __launch_bounds__(256) void qk_post_vec128_kernel(umv_qkv_post_args a) {
+    constexpr int HD = 128, HALF = 64;
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int nqk = a.nq + a.nkv, nheads = a.nq + 2 * a.nkv;
+    const int64_t item = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = item < (int64_t)a.T * nqk;
+    const int t = live ? (int)(item / nqk) : 0;
+    const int h = live ? (int)(item % nqk) : 0;
+    const bool is_q = h < a.nq;
+    const int pos = a.tok_pos[t];
+    const bf16_t* nw = is_q ? a.q_norm_w : a.k_norm_w;
+    if (a.expert && a.expert[t]) nw = is_q ? a.q_norm_w_gen : a.k_norm_w_gen;
+    auto ld4 = [](const bf16_t* p, float* o) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    };
+    const bf16_t* src = a.qkv + (int64_t)t * nheads * HD + (int64_t)h * HD + 4 * sub;
+    float x1[4], x2[4], c1[4], s1[4], c2[4], s2[4], w1[4], w2[4];
+    ld4(src, x1); ld4(src + HALF, x2);
+    ld4(a.cos_tab + (int64_t)pos * HD + 4 * sub, c1); ld4(a.sin_tab + (int64_t)pos * HD + 4 * sub, s1);
+    ld4(a.cos_tab + (int64_t)pos * HD + HALF + 4 * sub, c2); ld4(a.sin_tab + (int64_t)pos * HD + HALF + 4 * sub, s2);
+    ld4(nw + 4 * sub, w1); ld4(nw + HALF + 4 * sub, w2);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float q = x1[e] * x1[e] + x2[e] * x2[e];
+        q += row_xor<8>(q);      // lane bit 5 of the per-head wave
+        q += row_xor<4>(q);      // bit 4
+        q += row_xor<2>(q);      // bit 3
+        q += row_xor<1>(q);      // bit 2
+        v[e] = q;
+    }
+    const float ss = (v[0] + v[2]) + (v[1] + v[3]);       // bits 1, 0
+    const float rstd = rsqrt_ieee(ss / (float)HD + a.eps);
+    const bool gen = a.fp32_chain != 0;
+    float o1[4], o2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (!gen) {
+            const float n1 = rbf(w1[e] * rbf(x1[e] * rstd)), n2 = rbf(w2[e] * rbf(x2[e] * rstd));
+            o1[e] = rbf(rbf(n1 * c1[e]) + rbf(-n2 * s1[e]));
+            o2[e] = rbf(rbf(n2 * c2[e]) + rbf(n1 * s2[e]));
+        } else {
+            const float n1 = __fmul_rn(w1[e], __fmul_rn(x1[e], rstd)), n2 = __fmul_rn(w2[e], __fmul_rn(x2[e], rstd));
+            o1[e] = __fadd_rn(__fmul_rn(n1, c1[e]), __fmul_rn(-n2, s1[e]));
+            o2[e] = __fadd_rn(__fmul_rn(n2, c2[e]), __fmul_rn(n1, s2[e]));
+        }
+    }
+    if (!live) return;
+    bf16_t* dst = is_q ? a.q_out + (int64_t)t * a.nq * HD + (int64_t)h * HD
+                       : a.k_slab + a.tok_seg[t] * a.k_seg_stride + (h - a.nq) * a.k_head_stride + (int64_t)a.tok_slot[t] * HD;
+    u32x2 p1, p2;
+    p1.x = pack2bf(o1[0], o1[1]); p1.y = pack2bf(o1[2], o1[3]);
+    p2.x = pack2bf(o2[0], o2[1]); p2.y = pack2bf(o2[2], o2[3]);
+    *reinterpret_cast<u32x2*>(dst + 4 * sub) = p1;
+    *reinterpret_cast<u32x2*>(dst + HALF + 4 * sub) = p2;
+}
+
 extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     UMV_CHECK(ap, UMV_ERR_ARG, "qkv_post: null args");
     const umv_qkv_post_args& a = *ap;
@@ -767,6 +833,16 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
         hipLaunchKernelGGL(qkv_split_kernel, grid, block, 0, (hipStream_t)stream, a);
     } else {
         UMV_CHECK(a.hd == 128 || a.hd == 72, UMV_ERR_UNSUPPORTED, "qkv_post: head_dim %d unsupported (128, 72)", a.hd);
+        static int vec = -1;      // UMV_QKV_POST_VEC=0: the per-(token, head) wave for every size (A/B only)
+        if (vec < 0) { const char* e = getenv("UMV_QKV_POST_VEC"); vec = e ? atoi(e) : 1; }
+        if (vec && a.hd == 128 && !a.qkv_partials && a.T >= 64 && (a.v_d_stride % 8) == 0) {
+            const int64_t qk_items = (int64_t)a.T * (a.nq + a.nkv);
+            hipLaunchKernelGGL(qk_post_vec128_kernel, dim3((unsigned)((qk_items + 15) / 16)), block, 0, (hipStream_t)stream, a);
+            const int nv8 = a.nkv * a.hd / 8;
+            hipLaunchKernelGGL(v_transpose_kernel, dim3((unsigned)((a.T + 255) / 256), (unsigned)((nv8 + 7) / 8)), block, 0, (hipStream_t)stream, a);
+            UMV_LAUNCH_CHECK();
+            return UMV_OK;
+        }
         // (sending the V heads of a long prefill through the tile kernel and only q / k through this one was measured on the
         // flow passes, T = 2064: 20.4 + 11.4 us against 24.8 us in one kernel - the per-(token, head) wave with 2-byte
         // accesses is the cost here, not the V scatter)
