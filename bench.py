@@ -770,26 +770,31 @@ def main():
                 return v["avg_us"], v["calls"], (f * 2048.0 if f else None)
         return None
     def stage_counters(stage):
-        """MFMA-side counters of the busiest tiled-GEMM kernel of a stage (tools/roofline_profile.sh: rocprofv3 --pmc passes over
-        tools/stage_profile.py <stage>, same stamp rule as `traffic`); None when the profile is absent / stale"""
+        """MFMA-side counters of a stage's tiled-GEMM / prefill-attention kernels (tools/roofline_profile.sh: rocprofv3 --pmc passes
+        over tools/stage_profile.py <stage>, same stamp rule as `traffic`), busiest first (share = dispatches x busy cycles);
+        None when the profile is absent / stale"""
         rows = (prof or {}).get("stage_pmc", {}).get(stage) or {}
-        best = None
+        ent = []
         for name, c in rows.items():
-            if "gemm_tiled" not in name or "MfmaUtil" not in c:
+            if not isinstance(c, dict) or "MfmaUtil" not in c:
                 continue
-            if best is None or c["MfmaUtil"]["n"] > rows[best]["MfmaUtil"]["n"]:
-                best = name
-        if best is None:
+            busy = c.get("SQ_BUSY_CYCLES", {}).get("avg", 0.0) * c["MfmaUtil"]["n"]
+            short = name.split("Ev1")[0].replace("_Z17gemm_tiled_kernelI", "gemm_tiled<").replace("_Z19attn_prefill_kernelI", "attn_prefill<")
+            short = short.replace("ELi", ",").replace("Li", "").rstrip("E") + ">"
+            e = {"kernel": short, "dispatches": c["MfmaUtil"]["n"], "mfma_util_pct": round(c["MfmaUtil"]["avg"], 1)}
+            if "LdsUtil" in c:
+                e["lds_util_pct"] = round(c["LdsUtil"]["avg"], 1)
+            if "SQ_WAIT_INST_LDS" in c and c.get("SQ_BUSY_CYCLES", {}).get("avg"):
+                e["wait_inst_lds_per_busy_cycle"] = round(c["SQ_WAIT_INST_LDS"]["avg"] / c["SQ_BUSY_CYCLES"]["avg"], 3)
+            ent.append((busy, e))
+        if not ent:
             return None
-        c = rows[best]
-        out_c = {"kernel": best.split("Ev13")[0].replace("_Z17gemm_tiled_kernelI", "gemm_tiled<").replace("ELi", ",").replace("Li", "") + ">",
-                 "dispatches": c["MfmaUtil"]["n"], "mfma_util_pct": round(c["MfmaUtil"]["avg"], 1)}
-        if "LdsUtil" in c:
-            out_c["lds_util_pct"] = round(c["LdsUtil"]["avg"], 1)
-        if "SQ_WAIT_INST_LDS" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"]["avg"]:
-            out_c["wait_inst_lds_per_busy_cycle"] = round(c["SQ_WAIT_INST_LDS"]["avg"] / c["SQ_BUSY_CYCLES"]["avg"], 3)
-        out_c["source"] = "profiles/roofline_profile_latest.json (rocprofv3 --pmc, own passes, same kernel sources as this library)"
-        return out_c
+        ent.sort(key=lambda t: -t[0])
+        tot = sum(b for b, _ in ent) or 1.0
+        for b, e in ent:
+            e["share_of_profiled_busy_cycles"] = round(b / tot, 3)
+        return {"kernels": [e for _, e in ent[:4]],
+                "source": "profiles/roofline_profile_latest.json (rocprofv3 --pmc, one pass per counter set, same kernel sources as this library)"}
     dom_sub = "gemm_skinny_kernelILi1ELi2ELi4E"
     dom = prof_kernel(dom_sub)
     avg_us_replay = avg_us
