@@ -1,9 +1,13 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04_qkv; mkdir -p $O; rm -f $O/*.txt
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_engine_gpu.py tests/test_edge_gpu.py tests/test_inferencer_gpu.py -x -q 2>&1 | tail -3 | tee -a $O/tests.txt
-for V in 0 1; do
-  echo "== UMV_QKV_POST_VEC=$V" | tee -a $O/ab.txt
-  UMV_QKV_POST_VEC=$V timeout 300 python tools/stage_profile.py t2i 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/ab.txt
-  UMV_QKV_POST_VEC=$V REPS=10 timeout 300 python tools/stage_profile.py prefill 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/ab.txt
+O=gpurun_out/r04_tiles; mkdir -p $O; rm -f $O/t324.txt
+SH="2048,3584,18944;2048,3584,3584;515,3584,1160;300,448,96"
+for T in 268 324; do
+  echo "== tile $T" | tee -a $O/t324.txt
+  UMV_GEMM_TILE=$T SHAPES="$SH" timeout 300 python tools/gemm_ab.py 2>&1 | grep -v amdgpu.ids | tee -a $O/t324.txt
+done
+for SHP in 2048,3584,18944 2048,3584,3584 1024,3584,18944; do
+  for T in 268 324 270; do
+    SHAPE=$SHP SECONDS=2 UMV_GEMM_TILE=$T timeout 120 python tools/gemm_power.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/t324.txt
+  done
 done
