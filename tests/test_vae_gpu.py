@@ -89,6 +89,40 @@ def test_groupnorm(vae, C, hw, swish):
     assert bool((d <= tol).all()) and d.mean().item() < 3e-3, f"groupnorm C={C}: max {d.max().item()} mean {d.mean().item()}"
 
 
+def test_groupnorm_swish_every_bf16_value():
+    """the fused swish of umv_groupnorm_nhwc_bf16 uses v_exp_f32 / v_rcp_f32 (about 1 ulp each) where the reference
+    computes torch.sigmoid on a bf16 tensor - check ALL bf16 values (round 4 found and fixed the one range that differed: y <= -87.5,
+    where the clamped hardware exponent returned y * 2^-126 instead of the underflowing sigmoid's -0).  With gamma = 0 and beta = v the normalised value is exactly
+    v for every pixel, so 32 launches of 2048 channels push every finite bf16 pattern through y -> bf16(y * bf16(sigmoid(y)))."""
+    from unimedvl_amd import _lib
+    from unimedvl_amd.vae import _stream
+    lib = _lib.load()
+    C, hw = 2048, 4
+    bits = torch.arange(65536, dtype=torch.int32)
+    allv = bits.to(torch.int16).view(BF16)
+    x = torch.tensor([1.0, -1.0, 1.0, -1.0]).view(1, hw, 1).expand(1, hw, C).contiguous().to(BF16).cuda()
+    ws = torch.empty(lib.umv_groupnorm_workspace_bytes(1, hw) // 4 + 16, dtype=torch.float32, device="cuda")
+    gamma = torch.zeros(C, dtype=BF16, device="cuda")
+    out = torch.empty_like(x)
+    bad, worst, checked = 0, 0.0, 0
+    for i in range(65536 // C):
+        v = allv[i * C:(i + 1) * C]
+        beta = v.cuda()
+        _lib.check(lib.umv_groupnorm_nhwc_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), 1, hw, C, 1e-6, 1,
+                                               _stream()), "gn")
+        torch.cuda.synchronize()
+        got = out[0, 0].cpu()
+        fin = torch.isfinite(v.float())
+        ref = v * torch.sigmoid(v)                         # bf16 tensor ops: sigmoid rounded to bf16, product rounded to bf16
+        ne = (got.view(torch.int16) != ref.view(torch.int16)) & fin & ~((got.float() == 0) & (ref.float() == 0))
+        bad += int(ne.sum())
+        checked += int(fin.sum())
+        if ne.any():
+            worst = max(worst, float(((got.float() - ref.float()).abs() / ref.float().abs().clamp_min(1e-30))[ne].max()))
+    print(f"swish over all {checked} finite bf16 values: {bad} differ from torch (worst relative difference {worst:.4g})")
+    assert bad == 0, f"{bad} of {checked} bf16 values differ from torch.sigmoid's swish (worst relative difference {worst:.4g})"
+
+
 def test_attention_hd512():
     from unimedvl_amd import ops
     from oracle.unimedvl_cpu import attention_segment

@@ -720,7 +720,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         for (int j = 0; j < 8; ++j) {
             float y = rbf((bf2f((bf16_t)v[j]) - mean[j]) * rstd[j] * gw[j] + bw[j]);
             if (swish) {
-                const float sg = rbf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(-y * 1.4426950408889634f, 126.0f))));
+                // torch.sigmoid on the bf16 tensor, then the bf16 product.  v_exp_f32 / v_rcp_f32 give the same bf16 sigmoid as torch for
+                // EVERY bf16 y > -87.5 (tests/test_vae_gpu.py::test_groupnorm_swish_every_bf16_value walks all 65280 finite values);
+                // below that e^-y leaves the range the hardware units keep (denormal results flush), so those few values take IEEE
+                // division and libm's expf - y -> -0 once the sigmoid underflows, as in the reference.
+                float sg = rbf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(-y * 1.4426950408889634f, 126.0f))));
+                if (y < -87.0f) sg = rbf(__fdiv_rn(1.0f, 1.0f + expf(-y)));
                 y = rbf(y * sg);
             }
             o[j] = (short)f2bf(y);
