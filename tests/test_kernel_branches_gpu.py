@@ -277,6 +277,58 @@ print('sha swiglu', hashlib.sha256(o3.cpu().view(torch.int16).numpy().tobytes())
     assert shas["0"] == shas["1"], [(a, b) for a, b in zip(shas["0"], shas["1"]) if a != b]
 
 
+def test_skinny_full_line_x_staging_bit_identical(ops):
+    """The weight-streaming kernels with x in full 128-byte lines (gemm.hip XL, the default: a k-tile pair of 8 rows per load, per-wave
+    LDS staging, one piece for M <= 8, two per 16-row tile above) against the fragment-shaped loads they replaced
+    (UMV_SKINNY_XL=0 / UMV_SKINNY8_XL=0): same operands, same MFMAs, same order - every bit must agree.  Rows 1 .. 64, K slices that
+    start on odd k-tiles (K = 3584 over 3 splits: 38 / 8 waves = 5 tiles per wave), K % 64 != 0, K % 32 != 0, split-K partial sums,
+    SwiGLU, residual, row-indexed x, and the e4m3 kernels."""
+    import subprocess as sp
+    code = f"""
+import hashlib, sys, math, torch
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+from unimedvl_amd import ops
+from test_kernel_branches_gpu import rnd, BF16
+def sha(t): return hashlib.sha256(t.cpu().contiguous().view(torch.int16 if t.dtype == BF16 else torch.int32).numpy().tobytes()).hexdigest()[:16]
+for N, K in ((4608, 3584), (3584, 18944), (1000, 1096), (320, 4304), (96, 96)):
+    w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
+    for fp8 in (False, True):
+        if fp8 and K % 64:
+            continue
+        lin = (ops.PackedLinear.from_weight_fp8 if fp8 else ops.PackedLinear.from_weight)(w, b)
+        for M in (1, 7, 8, 9, 16, 17, 32, 33, 64):
+            x = rnd((M, K), 10 + M)
+            res = rnd((M, N), 4)
+            print('sha', N, K, fp8, M, sha(ops.gemm(x, lin, residual=res)))
+            if M in (8, 32) and N % 16 == 0:
+                for sk in (3, 4):
+                    part = torch.zeros((sk, M, N), dtype=torch.float32, device='cuda')
+                    ops.gemm_splitk(x, lin, part, sk)
+                    print('sha split', N, K, fp8, M, sk, sha(part))
+        T = 40
+        rows = torch.tensor([3, 9, 11, 20, 21, 22, 30, 31, 38, 39], dtype=torch.int32, device='cuda')
+        xs = rnd((T, K), 77)
+        o = torch.zeros((T, N), dtype=BF16, device='cuda')
+        ops.gemm(xs, lin, out=o, M=10, row_idx=rows)
+        print('sha rows', N, K, fp8, sha(o))
+g, u = rnd((1024, 3584), 6, 0.02), rnd((1024, 3584), 7, 0.02)
+for fp8 in (False, True):
+    lin = (ops.PackedLinear.from_gate_up_fp8 if fp8 else ops.PackedLinear.from_gate_up)(g, u)
+    for M in (8, 24, 48):
+        print('sha swiglu', fp8, M, sha(ops.gemm(rnd((M, 3584), 8), lin)))
+"""
+    shas = {}
+    for xl in ("0", "default"):
+        env = dict(os.environ)
+        if xl == "0":
+            env.update(UMV_SKINNY_XL="0", UMV_SKINNY8_XL="0")
+        r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        shas[xl] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
+        assert len(shas[xl]) > 90, len(shas[xl])
+    assert shas["0"] == shas["default"], [(a, b) for a, b in zip(shas["0"], shas["default"]) if a != b][:10]
+
+
 # ---------------------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, ks, vs, q_lens, causal):
     """flash-attn model in fp32 on the device: S = QK^T/sqrt(d) (+ bottom-right causal mask), fp32 softmax, P rounded to
