@@ -404,7 +404,7 @@ def test_configs1_long_free_running_decode_256(fw):
     interactive_vqa_inferencer.py:64).  B = 8, 448 x 448 + 32-token question (context 1060), 256 steps under the HIP graph in two
     sessions of 128: the second one makes the KV slabs GROW (capacity 1280 -> 2560: NaiveCache.ensure copies the committed
     keys into new slabs and the step is re-captured on the new addresses) and changes the key-split count of the decode
-    attention (19 -> 21 splits).  The engine decodes freely; the oracle is fed the engine's tokens, so every one of the 2048
+    attention (25 -> 28 splits).  The engine decodes freely; the oracle is fed the engine's tokens, so every one of the 2048
     greedy ids is checked (exactly, wherever the oracle's top-2 margin exceeds 0.25) and one near-tie cannot end the comparison."""
     from oracle.unimedvl_cpu import KVCache
     from unimedvl_amd.kvcache import NaiveCache

@@ -71,8 +71,12 @@ class DecodeSession:
             nsplit = int(os.environ["UMV_DECODE_NSPLIT"])   # tuning only
         # ... but no more than ~1024 waves in all: with many samples the partial (O, m, l) traffic and the combine grow with the
         # split count (B = 32, context 1156: 4.45 ms per step at 8 splits, 4.53 at 19; B = 8 is unchanged by the cap)
+        # round 4 (single-wave workgroups; profiles/r04_decode_nsplit_sweep.txt): B = 32, context 1156: 6 splits 4.009 ms, 8 splits 4.061,
+        # 4 splits 4.046, 12 splits 4.064; B = 8, context 1060: 24 splits 3.116, 17 splits 3.125, 28 splits 3.131 -> ~768 waves at
+        # 9 .. 32 samples (1024 otherwise: unmeasured, unchanged) and ~48 keys per split up to 8 samples
         if nsplit is None:
-            nsplit = max(1, min(32, (max_kv + 63) // 64, max(1, 1024 // (B * nkv))))
+            keys = 48 if B <= 8 else 64
+            nsplit = max(1, min(32, (max_kv + keys - 1) // keys, max(1, (768 if 8 < B <= 32 else 1024) // (B * nkv))))
         self.nsplit = nsplit
         self.ws = ops.attn_workspace(B, nq, hd, 1, self.nsplit, dev) if self.nsplit > 1 else None
         self.max_kv = max_kv
