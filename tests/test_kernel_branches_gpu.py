@@ -329,6 +329,54 @@ for fp8 in (False, True):
     assert shas["0"] == shas["default"], [(a, b) for a, b in zip(shas["0"], shas["default"]) if a != b][:10]
 
 
+def test_mid_batch_full_line_x_staging_bit_identical(ops):
+    """33..64-row wide-N GEMMs (128 x 64 tile, UMV_GEMM_M64_TILED 2 = full-line x staging, k-steps of 32; 1 = k-steps of 64, half lines)
+    and the 65..128-row split-K tile (UMV_SPLITK_TILED_XL 1 / 0): same operands, same k order per accumulator - every bit must agree.
+    Ragged rows, K % 64 != 0, odd K-range starts (K = 3584 over 3 / 7 splits), SwiGLU, bias + residual, row-indexed x."""
+    import subprocess as sp
+    code = f"""
+import hashlib, sys, math, torch
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+from unimedvl_amd import ops
+from test_kernel_branches_gpu import rnd, BF16
+def sha(t): return hashlib.sha256(t.cpu().contiguous().view(torch.int16 if t.dtype == BF16 else torch.int32).numpy().tobytes()).hexdigest()[:16]
+g, u = rnd((1024, 3584), 6, 0.02), rnd((1024, 3584), 7, 0.02)
+glin = ops.PackedLinear.from_gate_up(g, u)
+for M in (33, 40, 47, 64):
+    print('sha swiglu', M, sha(ops.gemm(rnd((M, 3584), 8), glin)))
+for N, K in ((16384, 3584), (18944, 1096), (20000, 4304)):
+    w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
+    lin = ops.PackedLinear.from_weight(w, b)
+    for M in (33, 50, 64):
+        x = rnd((M, K), 10 + M); res = rnd((M, N), 4)
+        print('sha wide', N, K, M, sha(ops.gemm(x, lin, residual=res)))
+    T = 80
+    rows = torch.randperm(T, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))[:45].sort().values.to(torch.int32)
+    xs = rnd((T, K), 77); o = torch.zeros((T, N), dtype=BF16, device='cuda')
+    ops.gemm(xs, lin, out=o, M=45, row_idx=rows)
+    print('sha rows', N, K, sha(o))
+for N, K in ((3584, 3584), (4608, 3584), (3584, 18944), (1008, 1096)):
+    w = rnd((N, K), 2, 1 / math.sqrt(K))
+    lin = ops.PackedLinear.from_weight(w)
+    for M in (65, 96, 127, 128):
+        x = rnd((M, K), 10 + M)
+        for sk in (2, 3, 7):
+            part = torch.zeros((sk, M, N), dtype=torch.float32, device='cuda')
+            ops.gemm_splitk(x, lin, part, sk)
+            print('sha split', N, K, M, sk, sha(part))
+"""
+    shas = {}
+    for v in ("old", "default"):
+        env = dict(os.environ)
+        if v == "old":
+            env.update(UMV_GEMM_M64_TILED="1", UMV_SPLITK_TILED_XL="0")
+        r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        shas[v] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
+        assert len(shas[v]) == 4 + 3 * 4 + 4 * 12, len(shas[v])
+    assert shas["old"] == shas["default"], [(a, b) for a, b in zip(shas["old"], shas["default"]) if a != b][:10]
+
+
 # ---------------------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, ks, vs, q_lens, causal):
     """flash-attn model in fp32 on the device: S = QK^T/sqrt(d) (+ bottom-right causal mask), fp32 softmax, P rounded to

@@ -1547,8 +1547,13 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (skinny_max < 0) { const char* e = getenv("UMV_GEMM_SKINNY_MAX"); skinny_max = e ? atoi(e) : 64; }
     static int sk_tiled_min = -1;   // tuning only: UMV_SPLITK_TILED_MIN=<rows from which split-K runs on the tiled kernel>
     if (sk_tiled_min < 0) { const char* e = getenv("UMV_SPLITK_TILED_MIN"); sk_tiled_min = e ? atoi(e) : 65; }
-    if (a.k_splits > 1 && (a.M > 64 || a.M >= sk_tiled_min) && TH == 16)    // 65..128 rows: the 128 x 128 tile (two workgroups per CU) over k_splits K ranges, fp32 partials
+    static int sk_xl = -1;          // UMV_SPLITK_TILED_XL=0: the half-line staging of the 65..128-row split-K tile (A/B, tuning only; bit-identical;
+                                    // full-line staging: 128-sample decode step 7.69 -> 7.62 ms, 96 samples 7.03 -> 6.87 ms)
+    if (sk_xl < 0) { const char* e = getenv("UMV_SPLITK_TILED_XL"); sk_xl = e ? atoi(e) : 1; }
+    if (a.k_splits > 1 && (a.M > 64 || a.M >= sk_tiled_min) && TH == 16) {  // 65..128 rows: the 128 x 128 tile (two workgroups per CU) over k_splits K ranges, fp32 partials
+        if (sk_xl) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
         return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);
+    }
     if (a.k_splits > 1) {
         // split-K decode GEMM: 4 n-tiles per workgroup share every x fragment (x re-reads from L2 drop 4x against the
         // one-tile workgroups), the K range is cut k_splits ways to keep >= 256 workgroups, partial sums go to fp32
@@ -1562,6 +1567,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
             if (v32 == 2) return launch_skinny<2, 2, 2, true, 0>(a, KT, NTT, s);
             return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
         }
+        // (33..64 rows on a tiled kernel over the K ranges - 128 x 64 full-line or UMV_SPLITK_TILED_MIN=33 - measured 6.25 / 6.45 ms per
+        // 64-sample step against 5.41: the weight-streaming kernel stays)
         return launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
     }
     if (a.M <= 64 && (a.M <= skinny_max || TH != 16)) {
@@ -1587,7 +1594,10 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // per 64 and streams gate/up in 73 us against 84 for the 4-tile skinny kernel (tools/stream_tile_bench.py 64); at
         // <= 32 rows the skinny kernel wins (60 vs 64-66 us).  Not with the argmax epilogue (skinny kernels only).
         static int m64 = -1;
-        if (m64 < 0) { const char* e = getenv("UMV_GEMM_M64_TILED"); m64 = e ? atoi(e) : 1; }
+        if (m64 < 0) { const char* e = getenv("UMV_GEMM_M64_TILED"); m64 = e ? atoi(e) : 2; }
+        // UMV_GEMM_M64_TILED=2 (default): the same tile with k-steps of 32 and x staged in full 128-byte lines (SCHED = 3, 48 KiB, 3 WG/CU):
+        // bit-identical, 64-sample decode step 5.65 -> 5.42 ms, 40 samples 4.82 -> 4.60 ms; 1 = the 64-wide k-step tile, 0 = skinny
+        if (two && TH == 16 && m64 == 2 && a.M > 32 && !a.argmax_partial && !a.norm_w && a.K >= 1024) return launch_tiled<4, 1, 2, 4, 1, 4, 3>(a, KT, NTT, s);
         if (two && TH == 16 && m64 && a.M > 32 && !a.argmax_partial && !a.norm_w && a.K >= 1024) return launch_tiled<4, 1, 2, 4, 2, 3>(a, KT, NTT, s);
         if (two && nt4 && TH == 16) return launch_skinny<4, 4, 1, true, 0>(a, KT, NTT, s);
         if (a.M <= 32) return two ? launch_skinny<2, 2, 4, false, 0>(a, KT, NTT, s) : launch_skinny<2, 1, 4, false, 0>(a, KT, NTT, s);
