@@ -1582,6 +1582,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // = M : 64); UMV_GEMM_SKINNY_NT=2 restores the 2-tile kernels (tuning only)
         static int nt4 = -1;
         if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : (e && atoi(e) == 8) ? 8 : 1; }
+        // (the 128 x 64 full-line tile at 17..32 rows: 32 samples 3.99 -> 4.09 ms per step, 24: 3.80 -> 3.92, 17: 3.62 -> 3.74 - the
+        // weight-streaming kernel keeps these rows; profiles/r04_midbatch_xline.txt)
         if (two && nt4 == 8 && TH == 16 && a.M <= 32) return launch_skinny<2, 8, 1, true, 0>(a, KT, NTT, s);
         if (two && nt4 && TH == 16 && a.M <= 32) {
             static int v32 = -1;
