@@ -72,6 +72,17 @@ def main():
             model.forward_cache_update_text(cache, **gi)
         return run
 
+    if os.environ.get("PREFETCH_N"):      # experiment: pull the packed weights of the GEMMs with these N through the caches right before the GEMM
+        from experimental import ops as xops
+        from unimedvl_amd import ops as _ops
+        ns = {int(v) for v in os.environ["PREFETCH_N"].split(",")}
+        real = _ops.gemm
+
+        def gemm_pf(x, lin, *a, **k):
+            if lin.N in ns and x.shape[0] > 128 and lin.wp is not None:
+                xops.prefetch(lin.wp, blocks=256)
+            return real(x, lin, *a, **k)
+        _ops.gemm = gemm_pf
     fn = {"vit": vit, "prefill": prefill}[stage]()
     fn()
     torch.cuda.synchronize()
