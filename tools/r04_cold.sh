@@ -1,4 +1,2 @@
 #!/bin/bash
-for rep in 1 2; do
-for pf in "" 1152 "1152,4304" "1152,4304,3456"; do echo -n "vit PREFETCH_N=$pf : "; PREFETCH_N=$pf REPS=30 python tools/stage_profile.py vit 2>&1 | tail -1; done
-done
+for t in 0 384 268 266; do echo "== UMV_GEMM_TILE=$t"; UMV_GEMM_TILE=$t python tools/vit_gemm_cold.py 8192 2>&1 | grep -E "^(out|fc2) "; UMV_GEMM_TILE=$t python tools/vit_gemm_cold.py 2048 2>&1 | grep -E "^(llm_qkv) "; done
