@@ -1559,8 +1559,6 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // one-tile workgroups), the K range is cut k_splits ways to keep >= 256 workgroups, partial sums go to fp32
         // (two n-tiles per workgroup at M <= 8 - twice the workgroups, 216-224 is less than one per CU - measured 3.199 vs
         // 3.176 ms per step: no)
-        // (7 n-tiles per workgroup x 8 K splits = exactly 256 workgroups for N = 3584 instead of 56 x 4 = 224: 3.30 vs 3.14 ms per 8-sample
-        // step, 4.18 vs 4.02 at 32 samples - 190 / 246 VGPRs, one workgroup per CU; profiles/r04_midbatch_xline.txt)
         if (a.M <= 16) return launch_skinny<1, 4, 2, true, 0>(a, KT, NTT, s);
         if (a.M <= 32) {
             static int v32 = -1;    // tuning only: UMV_SKINNY_M32=<0|1|2>
