@@ -1507,6 +1507,14 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
             const long t288 = (long)((M + 127) / 128) * (N / 288), c288 = (t288 + cus - 1) / cus * 36864;
             if (c288 * 6 < c384 * 5 && c288 * 6 < c266 * 5) return 288;
         }
+        // few rows on a wide N (the 8 x 34-token question prefill: 272 x 37888 is 297 tiles of 384 x 128 = two rounds for 1.16 rounds of
+        // work): 256 x 128 tiles at ~1.15x the cost per unit of area (444 tiles = two rounds of two thirds the size): 154 -> 134 us
+        // (profiles/r04_m272_tiles.txt); the same rule sends the 65..128-row decode gate/up GEMM to 148 tiles of 256 x 128 instead of 99 of
+        // 384 x 128: 128 samples 7.80 -> 7.47 ms per step, 96: 7.07 -> 6.76, 72: 6.50 -> 6.17 (profiles/r04_fewrow_tile.txt)
+        const long c268 = (wg258 + cus - 1) / cus * 32768 * 115 / 100;
+        static int fewrow = -1;      // UMV_GEMM_FEWROW=0: without this rule (A/B, tuning only)
+        if (fewrow < 0) { const char* e = getenv("UMV_GEMM_FEWROW"); fewrow = e ? atoi(e) : 1; }
+        if (fewrow && M <= 512 && c268 < c384 && c268 < c266) return 268;
         if (c384 * 10 < c266 * 9) return 384;
     }
     if (wg256 >= 144) return 266;
