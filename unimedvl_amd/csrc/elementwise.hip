@@ -201,6 +201,8 @@ extern "C" int umv_residual_rmsnorm_bf16(const float* partials, int n_splits, in
             case 2: UMV_RRN_LAUNCH(2, 2); break;
             case 3: UMV_RRN_LAUNCH(2, 3); break;
             case 4: UMV_RRN_LAUNCH(2, 4); break;
+            case 6: UMV_RRN_LAUNCH(2, 6); break;      // (65..128 samples: 6 / 8 / 8 splits)
+            case 8: UMV_RRN_LAUNCH(2, 8); break;
             default: UMV_RRN_LAUNCH(2, 0); break;
         }
     } else {
@@ -576,6 +578,19 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
                 const float b1 = a.qkv_bias ? bf2f(a.qkv_bias[col]) : 0.f, b2 = a.qkv_bias ? bf2f(a.qkv_bias[col + HALF]) : 0.f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
+                    if (s < a.n_splits) { x1 += t1[s]; x2 += t2[s]; }
+                if (a.qkv_bias) { x1 += b1; x2 += b2; }
+            } else if (a.n_splits <= 8) {   // 65..128 samples (6 splits): the same, eight wide
+                float t1[8], t2[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int ss = s < a.n_splits ? s : 0;
+                    t1[s] = p[ss * a.split_stride];
+                    t2[s] = p[ss * a.split_stride + HALF];
+                }
+                const float b1 = a.qkv_bias ? bf2f(a.qkv_bias[col]) : 0.f, b2 = a.qkv_bias ? bf2f(a.qkv_bias[col + HALF]) : 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
                     if (s < a.n_splits) { x1 += t1[s]; x2 += t2[s]; }
                 if (a.qkv_bias) { x1 += b1; x2 += b2; }
             } else {
