@@ -257,6 +257,12 @@ def test_kernel_policy_queries_need_no_gpu():
     assert lib.umv_gemm_tile_config(1026, 3584, 3584) == 270        # 128 x 128, two workgroups per CU
     assert lib.umv_gemm_tile_config(300, 1152, 608) == 64           # short K
     assert lib.umv_gemm_tile_config(8, 37888, 3584) == 0            # M <= 64: weight-streaming kernels
+    # few rows on a wide N (round 4): 256 x 128 tiles when they cost fewer rounds x area than 384 x 128 / 256 x 256
+    assert lib.umv_gemm_tile_config(272, 37888, 3584) == 268        # 8 x 34-token question prefill: 444 tiles instead of 297 of 384 x 128
+    assert lib.umv_gemm_tile_config(128, 37888, 3584) == 268        # 128-sample decode gate/up: 148 tiles instead of 99
+    assert lib.umv_gemm_tile_config(130, 37888, 3584) == 384        # 2 row blocks: 198 tiles of 384 x 128 stay one round
+    assert lib.umv_gemm_tile_config(512, 37888, 3584) == 384        # a single image's guided flow pass (unchanged)
+    assert lib.umv_gemm_tile_config(1024, 37888, 3584) == 266 and lib.umv_gemm_tile_config(2048, 37888, 3584) == 266
     # prefill attention: two q-tiles per wave from 512 workgroups on
     assert lib.umv_attn_prefill_tq(8, 28, 4, 128, 1026) == 2
     assert lib.umv_attn_prefill_tq(1, 28, 4, 128, 1026) == 1
