@@ -523,6 +523,136 @@ def test_edit_path_448_vae_encode_and_gen_prefill(fw):
     _check_kv(cache, oc, range(cfg.layers), 2e-2, "edit path, gen-mode prefill of the 786-token span")
 
 
+def _edit_contexts(model, vae, oracle, cfg, ntid, imgs_vae, imgs_vit, prompts, noises):
+    """The three contexts interleave_inference builds for [image, text] with understanding_output=False (inferencer.py:587-607):
+    gen = VAE span + ViT span + text; cfg_text = gen before the text item (the image alone); cfg_img = the text alone.
+    Built through the engine's prepare_* / forward_cache_update_* and through the oracle's update_*; returns both sides."""
+    from copy import deepcopy
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.kvcache import NaiveCache
+    B = len(prompts)
+    gen = NaiveCache(cfg.layers)
+    gi, kvl, rope = model.prepare_vae_images([0] * B, [0] * B, imgs_vae, lambda x: x, ntid)
+    gen = model.forward_cache_update_vae(vae, gen, noise=noises, **gi)
+    gi, kvl, rope = model.prepare_vit_images(kvl, rope, imgs_vit, lambda x: x, ntid)
+    gen = model.forward_cache_update_vit(gen, **gi)
+    cfg_text, kvl_t, rope_t = deepcopy(gen), list(kvl), list(rope)
+    gi, kvl, rope = model.prepare_prompts(kvl, rope, [str(i) for i in range(B)], IdTok(prompts), ntid)
+    gen = model.forward_cache_update_text(gen, **gi)
+    cfg_img = NaiveCache(cfg.layers)
+    gi, kvl_i, rope_i = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], IdTok(prompts), ntid)
+    cfg_img = model.forward_cache_update_text(cfg_img, **gi)
+    # oracle
+    ids = [[ntid["bos_token_id"]] + p + [ntid["eos_token_id"]] for p in prompts]
+    og = KVCache(cfg.layers, B)
+    okv, orope = oracle.update_vae(og, [0] * B, [0] * B, imgs_vae, ntid, noise=noises)
+    okv, orope = oracle.update_vit(og, okv, orope, imgs_vit, ntid)
+    ot, okv_t, orope_t = og.clone(), list(okv), list(orope)
+    okv, orope = oracle.update_text(og, okv, orope, ids)
+    oi = KVCache(cfg.layers, B)
+    okv_i, orope_i = oracle.update_text(oi, [0] * B, [0] * B, ids)
+    assert (okv, orope, okv_t, orope_t, okv_i, orope_i) == (kvl, rope, kvl_t, rope_t, kvl_i, rope_i)
+    return (gen, kvl, rope), (cfg_text, kvl_t, rope_t), (cfg_img, kvl_i, rope_i), (og, ot, oi)
+
+
+def _edit_flow(model, oracle, cfg, ntid, ctx, shapes, steps, seed):
+    """FlowSession with the generator script's edit settings (interactive_image_generator.py:303-306,365-371: cfg_text 4.0, cfg_img 2.0,
+    interval [0, 1], text_channel renorm, shift 3.0) over three DISTINCT contexts, against the oracle's generate_image on the same
+    noise; returns (engine latents, oracle latents, per-step (max, mean) deviations)."""
+    from unimedvl_amd.bagel import FlowSession
+    (gen, kvl, rope), (cfg_text, kvl_t, rope_t), (cfg_img, kvl_i, rope_i), (og, ot, oi) = ctx
+    torch.manual_seed(seed)
+    gl = model.prepare_vae_latent(kvl, rope, shapes, ntid)
+    gt = model.prepare_vae_latent_cfg(kvl_t, rope_t, shapes)
+    gim = model.prepare_vae_latent_cfg(kvl_i, rope_i, shapes)
+    noise = gl["packed_init_noises"].clone()
+    args = dict(gl)
+    args.update(dict(past_key_values=gen, num_timesteps=steps, timestep_shift=3.0, cfg_renorm_min=0.0, cfg_renorm_type="text_channel",
+                     cfg_interval=(0.0, 1.0), cfg_text_scale=4.0, cfg_img_scale=2.0,
+                     cfg_text_past_key_values=cfg_text, cfg_text_packed_position_ids=gt["cfg_packed_position_ids"],
+                     cfg_img_past_key_values=cfg_img, cfg_img_packed_position_ids=gim["cfg_packed_position_ids"]))
+    sess = FlowSession(model, args)
+    assert sess.nctx == 3 and sess.use_img and not sess.img_same, "the edit flow must run three DISTINCT contexts per guided step"
+    trace = []
+    while not sess.finished:
+        sess.step(1)
+        trace.append(sess.x_t.clone())
+    assert len(trace) == steps - 1
+    otrace = []
+    olat = oracle.generate_image(og, rope, shapes, noise, ntid, num_timesteps=steps, timestep_shift=3.0, cfg_interval=(0.0, 1.0),
+                                 cfg_text_scale=4.0, cfg_text=(ot, rope_t), cfg_img_scale=2.0, cfg_img=(oi, rope_i),
+                                 cfg_renorm_min=0.0, cfg_renorm_type="text_channel", trace=otrace)
+    per_step = []
+    for x, ox in zip(trace, otrace):
+        d = (x.cpu().float() - ox.float()).abs()
+        per_step.append((d.max().item(), d.mean().item()))
+    assert list(gen.lens) == kvl and list(cfg_text.lens) == kvl_t and list(cfg_img.lens) == kvl_i, "flow passes must not commit KV"
+    return sess.latents(), olat, per_step, otrace[-1].float().abs().max().item()
+
+
+# bounds of the edit-pipeline tests (measured distribution printed by the tests with -s and quoted in DESIGN.md section 3)
+EDIT_LAT_MAX, EDIT_LAT_MEAN, EDIT_PIX_WITHIN2, EDIT_PIX_MAX = 0.25, 0.03, 97.0, 24
+
+
+def test_edit_pipeline_512_three_contexts_text_channel(fw):
+    """The reference's flagship edit flow at FULL width (interactive_image_generator.py:290-397 -> inferencer.py:587-607 ->
+    bagel.py:1138-1186): a 448 x 448 input becomes a 512 x 512 VAE image (vae_transform min side 512, inferencer.py:42-70) and a
+    448 x 448 ViT image; gen context = VAE span (1026) + ViT span (1026) + 32-token instruction, cfg_text = the image alone,
+    cfg_img = the instruction alone - three DISTINCT contexts (asserted), so every guided step is three LLM passes over 1026
+    query tokens combined by the `text_channel` renorm (bagel.py:1173-1186) with cfg_text 4.0 / cfg_img 2.0 over the whole interval.
+    12 timesteps = 11 guided Euler steps; latent after every step and the final uint8 pixels (engine latent -> engine VAE against
+    oracle latent -> oracle VAE at 512 x 512) against OracleBagel."""
+    model, vae, oracle, cfg, ntid = fw
+    img448 = _synth_image(448, 448, 701)
+    img512 = torch.nn.functional.interpolate(img448[None], size=(512, 512), mode="bicubic", align_corners=False)[0].clamp(-1, 1).contiguous()
+    g = torch.Generator().manual_seed(702)
+    noise = torch.randn(1, cfg.z_channels, 512 // 8, 512 // 8, generator=g).to(BF16)
+    prompts = _prompts([32], 703)
+    ctx = _edit_contexts(model, vae, oracle, cfg, ntid, [img512], [img448], prompts, noise)
+    (gen, kvl, rope), (cfg_text, kvl_t, _), (cfg_img, kvl_i, _), (og, ot, oi) = ctx
+    assert kvl == [1026 + 1026 + 34] and kvl_t == [2052] and kvl_i == [34]
+    _check_kv(gen, og, range(cfg.layers), 2e-2, "edit pipeline, gen context (VAE + ViT + text)")
+    _check_kv(cfg_img, oi, range(cfg.layers), 2e-2, "edit pipeline, cfg_img context (text alone)")
+    steps = 12
+    lat, olat, per_step, rng = _edit_flow(model, oracle, cfg, ntid, ctx, [(512, 512)], steps, 704)
+    mx = [p[0] for p in per_step]
+    print(f"edit pipeline 512x512, 3 distinct contexts, text_channel: latent |diff| max per step {[round(v, 4) for v in mx]}; "
+          f"mean at the last step {per_step[-1][1]:.5f} (latent range {rng:.2f})")
+    assert max(mx) <= EDIT_LAT_MAX and per_step[-1][1] <= EDIT_LAT_MEAN, f"latent max {max(mx)} mean(last) {per_step[-1][1]}"
+    px = vae.decode_tokens_to_uint8(lat[0], (512, 512), model.latent_downsample, model.latent_patch_size).cpu()
+    ref = oracle.decode_image(olat[0], (512, 512))
+    assert px.shape == ref.shape == (512, 512, 3)
+    diff = (px.int() - ref.int()).abs()
+    dist = {k: round(100 * (diff <= k).float().mean().item(), 3) for k in (0, 1, 2, 4, 8, 16)}
+    print(f"edit pipeline 512x512: END-TO-END uint8 pixels: % within k grey levels {dist}, max {diff.max().item()}, mean {diff.float().mean().item():.3f}")
+    assert dist[2] >= EDIT_PIX_WITHIN2 and diff.max().item() <= EDIT_PIX_MAX, f"pixels: {dist}, max {diff.max().item()}"
+
+
+def test_edit_pipeline_ragged_batch_of_two(fw):
+    """The same flow as a RAGGED packed batch of two requests (the batch extension of the entry points): different input / output
+    sizes (256 x 384 and 320 x 320 VAE images, 224 x 336 and 280 x 280 ViT images) and instruction lengths (20 / 32 tokens); the
+    `text_channel` renorm is per token, so the packed oracle run is the per-request reference."""
+    model, vae, oracle, cfg, ntid = fw
+    sizes_vae, sizes_vit = [(256, 384), (320, 320)], [(224, 336), (280, 280)]
+    imgs_vae = [_synth_image(h, w, 711 + i) for i, (h, w) in enumerate(sizes_vae)]
+    imgs_vit = [torch.nn.functional.interpolate(im[None], size=s, mode="bilinear", align_corners=False)[0].contiguous()
+                for im, s in zip(imgs_vae, sizes_vit)]
+    g = torch.Generator().manual_seed(712)
+    mh, mw = max(h for h, _ in sizes_vae), max(w for _, w in sizes_vae)
+    noise = torch.randn(2, cfg.z_channels, mh // 8, mw // 8, generator=g).to(BF16)
+    prompts = _prompts([20, 32], 713)
+    ctx = _edit_contexts(model, vae, oracle, cfg, ntid, imgs_vae, imgs_vit, prompts, noise)
+    (gen, kvl, rope), _, _, (og, ot, oi) = ctx
+    _check_kv(gen, og, range(cfg.layers), 2e-2, "ragged edit batch, gen context")
+    lat, olat, per_step, rng = _edit_flow(model, oracle, cfg, ntid, ctx, sizes_vae, 7, 714)
+    mx = [p[0] for p in per_step]
+    print(f"ragged edit batch (256x384 + 320x320): latent |diff| max per step {[round(v, 4) for v in mx]}; mean at the last step "
+          f"{per_step[-1][1]:.5f} (latent range {rng:.2f})")
+    assert max(mx) <= EDIT_LAT_MAX and per_step[-1][1] <= EDIT_LAT_MEAN
+    for b, (h, w) in enumerate(sizes_vae):
+        assert lat[b].shape == olat[b].shape == ((h // 16) * (w // 16), 64)
+
+
 def test_configs4_mixed_fullwidth(fw):
     """configs[4] as written: e4m3 weights + e4m3 activations (W8A8), VQA requests and text-to-image requests IN ONE STEP
     STREAM (serving.MixedBatcher) at the full widths: 4 VQA slots (448 x 448 image + 32-token question) decode while a

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 #include "gemm_epilogue.h"
+#include "gemm_internal.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -1621,6 +1622,19 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         static int xline = -1;
         if (xline < 0) { const char* e = getenv("UMV_GEMM_XLINE"); xline = e ? atoi(e) : 1; }      // (2: also the 288-column tile, under evaluation)
         if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : (cfg == 288 && xline > 1) ? 388 : cfg;
+    }
+    {   // round 5: the 4-wave tiles with the accumulators in AGPRs (gemm_w4.hip) take over the 8-wave tiles of the same shape;
+        // bit-identical results (same MFMAs, operands and k order).  UMV_GEMM_W4=0: the 8-wave tiles (A/B, tuning only)
+        static int w4 = -1;
+        if (w4 < 0) { const char* e = getenv("UMV_GEMM_W4"); w4 = e ? atoi(e) : 0; }
+        if (w4 && !(a.epilogue & UMV_EPI_OUT_F32) && a.k_splits <= 1) {
+            const int c4 = cfg == 366 ? 466 : cfg == 368 ? 468 : cfg == 484 ? 4384 : 0;
+            if (c4 && (w4 == 1 || w4 == c4)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
+        }
+    }
+    if (cfg == 466 || cfg == 468 || cfg == 4384 || cfg == 4664 || cfg == 4684 || cfg == 94661 || cfg == 94664 || cfg == 94662) {
+        UMV_CHECK(!(a.epilogue & UMV_EPI_OUT_F32) && a.k_splits <= 1, UMV_ERR_UNSUPPORTED, "gemm: the 4-wave tiles write bf16 and take no K split");
+        return umv_gemm_w4_launch(a, KT, NTT, cfg, raster_gn(), s);
     }
     // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)
     if (cfg == 332) return launch_tiled<4, 1, 2, 2, 4, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 128, 3 buffers (120 KiB), 4 waves
