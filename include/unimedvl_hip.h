@@ -91,6 +91,9 @@ typedef struct {
                                  (order-preserving image of the stored bf16 logit) << 32 | (0xFFFFFFFF - column); the maximum
                                  key over a row is torch.argmax(logits) (lowest index on ties, NaN highest).  Finished by
                                  umv_decode_step_end_argmax.  The logits are still written to `out`. */
+    int64_t x_rows;           /* with row_idx: number of rows of the buffer `x` points into (rows row_idx may name), 0 = unknown.
+                                 The 4-wave tiles of the M > 64 path address x through 32-bit offsets and take a row-indexed call
+                                 only when x_rows * ldx * 2 < 2 GiB is known; unknown keeps the 8-wave tiles (same results). */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 /* Host-only query: the tiled-kernel configuration umv_gemm_bf16 picks for an M x N x K problem (0 for M <= 64, the

@@ -1627,15 +1627,10 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // bit-identical results (same MFMAs, operands and k order).  UMV_GEMM_W4=0: the 8-wave tiles (A/B, tuning only)
         static int w4 = -1;
         if (w4 < 0) { const char* e = getenv("UMV_GEMM_W4"); w4 = e ? atoi(e) : 0; }
-        if (w4 && !(a.epilogue & UMV_EPI_OUT_F32) && a.k_splits <= 1) {
-            const int c4 = cfg == 366 ? 466 : cfg == 368 ? 468 : cfg == 484 ? 4384 : 0;
-            if (c4 && (w4 == 1 || w4 == c4)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
-        }
+        const int c4 = cfg == 366 ? 466 : cfg == 368 ? 468 : cfg == 484 ? 4384 : 0;
+        if (w4 && c4 && (w4 == 1 || w4 == c4) && umv_gemm_w4_can_take(a, KT, NTT)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
     }
-    if (cfg == 466 || cfg == 468 || cfg == 4384 || cfg == 4664 || cfg == 4684 || cfg == 94661 || cfg == 94664 || cfg == 94662) {
-        UMV_CHECK(!(a.epilogue & UMV_EPI_OUT_F32) && a.k_splits <= 1, UMV_ERR_UNSUPPORTED, "gemm: the 4-wave tiles write bf16 and take no K split");
-        return umv_gemm_w4_launch(a, KT, NTT, cfg, raster_gn(), s);
-    }
+    if (cfg == 466 || cfg == 468 || cfg == 4384 || cfg == 94661 || cfg == 94662) return umv_gemm_w4_launch(a, KT, NTT, cfg, raster_gn(), s);
     // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)
     if (cfg == 332) return launch_tiled<4, 1, 2, 2, 4, 3>(a, KT, NTT, s);      // 128(n) x 32(m) x 128, 3 buffers (120 KiB), 4 waves
     if (cfg == 333) return launch_tiled<4, 1, 2, 2, 2, 4>(a, KT, NTT, s);      // 128(n) x 32(m) x 64, 4 buffers (80 KiB)

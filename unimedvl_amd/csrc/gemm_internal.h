@@ -50,5 +50,7 @@ static inline int umv_tile_superblock(int mblocks, int BM, int K) {
     return ms;
 }
 
-// gemm_w4.hip: 4-wave tiles with the accumulators in AGPRs (cfg 466 / 468 / 4384); bf16 output, no split-K
+// gemm_w4.hip: 4-wave tiles with the accumulators in AGPRs (cfg 466 / 468 / 4384); bf16 output, no split-K, operands within
+// 2 GiB of their base pointers (umv_gemm_w4_can_take)
+bool umv_gemm_w4_can_take(const umv_gemm_args& a, int KT, int NTT);
 int umv_gemm_w4_launch(const umv_gemm_args& a, int KT, int NTT, int cfg, int gn, hipStream_t s);

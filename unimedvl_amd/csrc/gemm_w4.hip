@@ -33,6 +33,13 @@ template <int IDX>
 __device__ __forceinline__ void w4_mfma(const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(IDX * 4), "n"(IDX * 4 + 3));
 }
+__host__ __device__ constexpr int w4_filler_at(int slot, int nf, int span) {
+    for (int k = 0; k < nf; ++k)
+        if (k * span / nf == slot) return k;
+    return -1;
+}
+// the compiler must treat a fragment as rewritten (an asm ds_read filled it behind its back, a counted wait has just retired it)
+__device__ __forceinline__ void w4_touch(bf16x8& f) { asm volatile("" : "+v"(f)); }
 // ABL = 2 (timing study): s_memtime stamps; the value arrives like a scalar load, the caller consumes it behind an lgkmcnt(0)
 __device__ __forceinline__ void w4_stamp(uint64_t& t) { asm volatile("s_memtime %0" : "=s"(t)); }
 template <int R>
@@ -42,24 +49,34 @@ __device__ __forceinline__ float w4_acc_read() {
     return v;
 }
 
-// NWS = slots of the W ring (3: W(t+3) is staged while tile t computes; 4: one more k-step of look-ahead, the tile's bias then comes
-// from global memory - the rings take all 160 KiB).  ABL (TIMING ONLY, wrong results): 1 = the K advance wraps every 8 k-steps, so
-// that every piece after the first pass is an L2 hit; 2 = the first 8 workgroups log five s_memtime stamps per k-step of steps 16..79
-// (body entry, my pieces landed, barrier passed, last MFMA issued, fragments landed) to (uint64_t*)a.w_scale - tools/w4_trace.py.
-template <int WN, int WM, int TN, int TM, int NWS = 3, int ABL = 0>
+// ABL (TIMING ONLY, wrong results; UMV_GEMM_ABLATIONS builds): 1 = the K advance wraps every 8 k-steps (every piece an L2 hit);
+// 2 = the first 8 workgroups log s_memtime stamps per k-step of steps 16..79 to (uint64_t*)a.w_scale - tools/w4_trace.py.
+// RAGK: K % 32 != 0 - the x chunks of the last k-step that lie beyond K are staged as zeros (out-of-range buffer offsets).
+//
+// Schedule of one k-step ("body" s; the fragments of tile s are in registers, read during body s-1):
+//     MFMA 0 .. QB-1        tile s, groups of TM MFMAs per W fragment; before group t a counted lgkmcnt wait for W fragment t
+//     s_waitcnt vmcnt(NP) lgkmcnt(0); s_barrier      my pieces of tile s+1 have landed / everyone's; everyone's reads of tile s done
+//     MFMA QB .. NMMA-1     with, between them: the 16 fragment reads of tile s+1 (x first, then W in the order the next body's
+//                           groups need them) and the NP LDS-DMA pieces of W(s+3) and of half an x pair
+//  -> nothing but MFMAs at the boundary between two bodies: the matrix pipe keeps running while the waves drift back into step at
+//     the barrier in the MIDDLE of a body (round 5 trace of the barrier-first form: 1650 cycles per k-step for 1024 of MFMAs,
+//     ~420 of them between the last MFMA of a step and the first of the next: profiles/r05_w4_v1_kstep_trace.txt).
+// The loop is unrolled over the period of the rings (6 k-steps), so every LDS address is a constant, and the pieces are
+// buffer_load_dwordx4 ... offen lds with ONE offset VGPR per piece for the whole kernel; K advances in the scalar offset
+// (clamped at the last k-tile / pair: the trailing bodies re-stage data nobody reads).
+template <int WN, int WM, int TN, int TM, int ABL = 0, bool RAGK = false>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn, int ms) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16;
-    constexpr int WPW = (WTILES + NW - 1) / NW, XPP = (BM / 8) / NW, XPB = XPP / 2, NP = WPW + XPB;
-    constexpr int WSLOT = WTILES * 1024, XSLOT = BM * 128, XBASE = NWS * WSLOT;
-    constexpr int STAGE_BYTES = NWS * WSLOT + 3 * XSLOT;
-    constexpr bool BIAS_LDS = STAGE_BYTES + BN * 2 <= 160 * 1024;
-    static_assert(NWS == 3 || NWS == 4, "W ring depth");
+    constexpr int WPW = WTILES / NW, XPP = (BM / 8) / NW, XPB = XPP / 2, NP = WPW + XPB;
+    constexpr int WSLOT = WTILES * 1024, XSLOT = BM * 128, XBASE = 3 * WSLOT;
+    constexpr int STAGE_BYTES = 3 * WSLOT + 3 * XSLOT;
     constexpr int NRD = TN + TM, NMMA = TN * TM, NACC = NMMA * 4;
+    constexpr int QB = 2 * TM;                       // the barrier sits behind the first two groups
     static_assert(NW == 4, "one wave per SIMD");
     static_assert(WTILES % NW == 0 && (BM / 8) % NW == 0 && XPP % 2 == 0, "even split of the staging pieces over the waves");
-    static_assert(NACC <= 256 && NRD <= NMMA && NP <= NMMA, "accumulators fit the AGPR file; at most one read / piece per MFMA");
+    static_assert(NACC <= 256 && NRD + NP <= NMMA - QB, "accumulators fit the AGPR file; at most one read / piece per MFMA behind the barrier");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,162 +95,157 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
     const int nt_blk = nblk * (BN / 16);
     const int nt_base = nt_blk + wn * TN;
     bf16_t* bias_lds = reinterpret_cast<bf16_t*>(smem + STAGE_BYTES);
-    if (BIAS_LDS && (a.epilogue & UMV_EPI_BIAS) && tid < BN) {
+    if ((a.epilogue & UMV_EPI_BIAS) && tid < BN) {
         const int n = nt_blk * 16 + tid;
         bias_lds[tid] = n < a.N ? a.bias[n] : (bf16_t)0;
     }
-    if constexpr (BIAS_LDS && BN > NW * 64) {
+    if constexpr (BN > NW * 64) {
         if ((a.epilogue & UMV_EPI_BIAS) && tid + NW * 64 < BN) {
             const int n = nt_blk * 16 + tid + NW * 64;
             bias_lds[tid + NW * 64] = n < a.N ? a.bias[n] : (bf16_t)0;
         }
     }
-    const int KTL = KT;
-    const int nsteps = KTL;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_w4);
-    const int kx_rel = a.K;
-    const bf16_t* curW[WPW];
-    int bumpW[WPW];
-    const bf16_t* curX[XPP];
+    const int nsteps = KT;
+    const int q_last = (a.K - 1) >> 6;               // the last k-step pair that holds data
+    // ---- the staging pieces: one 32-bit offset per piece, relative to a.wp / a.x, valid for every k-step
+    // W: n-tiles past NTT are clamped to the last one (their columns are never stored); x: rows past M are clamped likewise
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7FFFFFFF, 0x00020000);
+    uint32_t offW[WPW], offX[XPP];
     const int xchunk = (lane & 7) ^ ((lane >> 3) & 7);
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int nt = nt_blk + wave * WPW + i;
-        const bool ok = nt < NTT;
-        curW[i] = ok ? a.wp + ((int64_t)nt * KT) * 512 + lane * 8 : zero;
-        bumpW[i] = ok ? 512 : 0;
+        const int nt = min(nt_blk + wave * WPW + i, NTT - 1);
+        offW[i] = (uint32_t)nt * (uint32_t)KT * 1024u + lane * 16;
     }
 #pragma unroll
     for (int i = 0; i < XPP; ++i) {
         const int m = m0 + (wave * XPP + i) * 8 + (lane >> 3);
-        const int mm = m < a.M ? m : a.M - 1;                // rows past M are clamped (their outputs are masked)
+        const int mm = m < a.M ? m : a.M - 1;
         const int64_t row = a.row_idx ? (int64_t)a.row_idx[mm] : (int64_t)mm;
-        curX[i] = a.x + row * a.ldx + xchunk * 8;
+        offX[i] = (uint32_t)((row * a.ldx + xchunk * 8) * 2);
     }
-    auto dstW = [&](int slot, int i) -> char* { return smem + slot * WSLOT + (wave * WPW + i) * 1024; };
-    auto dstX = [&](int slot, int i) -> char* { return smem + XBASE + slot * XSLOT + (wave * XPP + i) * 1024; };
-    const bf16_t* pw[WPW];
-    const bf16_t* px[XPB];
-    auto prep_w = [&](int kt) {                 // the W pieces of k-tile kt: zero page past the K range
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) {
-            pw[i] = kt < KTL ? curW[i] : zero;
-            curW[i] += bumpW[i];
-            if constexpr (ABL == 1) { if ((kt & 7) == 7) curW[i] -= 8 * bumpW[i]; }
-        }
+    // RAGK: lanes whose 8 k of the last pair lie beyond K read out of range (zeros)
+    const bool xtail = RAGK && (q_last * 64 + xchunk * 8 >= a.K);
+    // scalar K offsets of the group the next body stages
+    // (char* and a cast at the call: a lambda RETURNING an address_space(3) pointer makes the host pass drop the kernel's stub)
+    auto lds_of = [&](int byte) -> char* { return smem + byte; };
+    auto stage_w = [&](int kt, auto SLOT, auto I) {
+        constexpr int slot = decltype(SLOT)::value, i = decltype(I)::value;
+        int ktc = min(kt, KT - 1);
+        if constexpr (ABL == 1) ktc &= 7;
+        const uint32_t off = offW[i];          // (passed directly, the array element makes the host pass drop the kernel stub)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_w4_t)lds_of(slot * WSLOT + (wave * WPW + i) * 1024), 16, off, ktc * 1024, 0, 0);
     };
-    auto prep_x = [&](int q, auto HALF) {       // pieces [HALF * XPB, +XPB) of k-step pair q: per-lane zero fill at the K tail
-        constexpr int hf = decltype(HALF)::value;
-        const int k0 = q * 64;
-        if (k0 + 64 <= kx_rel) {
-#pragma unroll
-            for (int i = 0; i < XPB; ++i) {
-                px[i] = curX[hf * XPB + i];
-                curX[hf * XPB + i] += 64;
-                if constexpr (ABL == 1) { if ((q & 3) == 3) curX[hf * XPB + i] -= 4 * 64; }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < XPB; ++i) { px[i] = (k0 + xchunk * 8 < kx_rel) ? curX[hf * XPB + i] : zero; curX[hf * XPB + i] += 64; }
-        }
+    auto stage_x = [&](int q, auto SLOT, auto HALF, auto I) {
+        constexpr int slot = decltype(SLOT)::value, hf = decltype(HALF)::value, i = decltype(I)::value;
+        int qc = min(q, q_last);
+        uint32_t off = offX[hf * XPB + i];
+        if constexpr (RAGK) off = (xtail && qc == q_last) ? 0x80000000u : off;
+        if constexpr (ABL == 1) qc &= 3;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_w4_t)lds_of(XBASE + slot * XSLOT + (wave * XPP + hf * XPB + i) * 1024), 16, off, qc * 128, 0, 0);
     };
-    // prologue, in the order the loop would have issued it.  NWS = 3: x pair 0, W(0), x pair 1, W(1), first half of x pair 2, W(2);
-    // NWS = 4: x pair 0, W(0), first half of pair 1, W(1), second half, W(2), first half of pair 2, W(3)
-    auto issue_x = [&](int q, auto HALF) {
-        constexpr int hf = decltype(HALF)::value;
-        prep_x(q, HALF);
-#pragma unroll
-        for (int i = 0; i < XPB; ++i) __builtin_amdgcn_global_load_lds((const void*)px[i], (lds_ptr_w4_t)dstX(q % 3, hf * XPB + i), 16, 0, 0);
-    };
-    auto issue_w = [&](int t) {
-        prep_w(t);
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) __builtin_amdgcn_global_load_lds((const void*)pw[i], (lds_ptr_w4_t)dstW(t % NWS, i), 16, 0, 0);
-    };
-    constexpr std::integral_constant<int, 0> H0{};
-    constexpr std::integral_constant<int, 1> H1{};
-    issue_x(0, H0); issue_x(0, H1); issue_w(0);
-    if constexpr (NWS == 3) {
-        issue_x(1, H0); issue_x(1, H1); issue_w(1);
-        issue_x(2, H0); issue_w(2);
-    } else {
-        issue_x(1, H0); issue_w(1);
-        issue_x(1, H1); issue_w(2);
-        issue_x(2, H0); issue_w(3);
-    }
+    // prologue, in the order the loop would have issued it: x pair 0, W(0), x pair 1, W(1), first half of x pair 2, W(2)
+    static_for<0, 3>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        static_for<0, XPB>([&](auto I) { stage_x(t, T, std::integral_constant<int, 0>{}, I); });
+        if constexpr (t < 2) static_for<0, XPB>([&](auto I) { stage_x(t, T, std::integral_constant<int, 1>{}, I); });
+        static_for<0, WPW>([&](auto I) { stage_w(t, T, I); });
+    });
     bf16x8 wfA[TN], xfA[TM], wfB[TN], xfB[TM];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_w4_t)smem;
-    const uint32_t woff = wn * TN * 1024 + lane * 16;
+    const uint32_t wbase = lds0 + wn * TN * 1024 + lane * 16;
     // x fragment of k half h: row (wm * TM + j) * 16 + r, chunk (4h + g) ^ (r & 7)
-    const uint32_t xoff0 = XBASE + (wm * TM * 16 + r) * 128 + ((g ^ (r & 7)) << 4), xoff1 = xoff0 ^ 64;
-    auto land = [&](bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(wf[t]));
-#pragma unroll
-        for (int j = 0; j < TM; ++j) asm volatile("" : "+v"(xf[j]));
+    const uint32_t xbase0 = lds0 + XBASE + (wm * TM * 16 + r) * 128 + ((g ^ (r & 7)) << 4), xbase1 = xbase0 ^ 64;
+    const uint32_t xbase0_hi = xbase0 + 65536, xbase1_hi = xbase1 + 65536;
+    // fragment read number rd of tile (slot sw, pair slot sx, k half h): x fragments first, then the W fragments in group order
+    auto read_frag = [&](auto RD, auto SW, auto SX, auto HALF, bf16x8(&wf)[TN], bf16x8(&xf)[TM]) {
+        constexpr int rd = decltype(RD)::value, sw = decltype(SW)::value, sx = decltype(SX)::value, h = decltype(HALF)::value;
+        if constexpr (rd < TM) {
+            constexpr int off = sx * XSLOT + rd * 2048;          // (the instruction's offset field has 16 bits)
+            if constexpr (off < 65536) w4_lds_read_frag<off>(xf[rd], h ? xbase1 : xbase0);
+            else w4_lds_read_frag<off - 65536>(xf[rd], h ? xbase1_hi : xbase0_hi);
+        } else {
+            static_assert(2 * WSLOT + (TN - 1) * 1024 < 65536, "W fragment offsets fit the instruction");
+            w4_lds_read_frag<sw * WSLOT + (rd - TM) * 1024>(wf[rd - TM], wbase);
+        }
     };
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWS == 3 ? 3 * XPB + 2 * WPW : 3 * NP) : "memory");      // x pair 0 and W(0) landed; what was issued behind them may fly
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * XPB + 2 * WPW) : "memory");      // x pair 0 and W(0) landed; what was issued behind them may fly
     UMV_BARRIER();
-    static_for<0, TN>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        w4_lds_read_frag<t * 1024>(wfA[t], lds0 + woff);
-    });
-    static_for<0, TM>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        w4_lds_read_frag<j * 2048>(xfA[j], lds0 + xoff0);
-    });
-    land(wfA, xfA);
-    auto body = [&](auto EVEN, int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
-        constexpr bool even = decltype(EVEN)::value;
-        uint64_t ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+    static_for<0, NRD>([&](auto RD) { read_frag(RD, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, wfA, xfA); });
+
+    // body U (compile time: position in the period of 6) of k-step `step`
+    auto body = [&](auto UC, int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
+        constexpr int u = decltype(UC)::value;
+        constexpr bool even = (u & 1) == 0;
+        constexpr int sw_next = (u + 1) % 3, sx_next = ((u + 1) >> 1) % 3;        // slots of tile step + 1
+        constexpr int sw_stage = u % 3, sx_stage = ((u + 5) >> 1) % 3;            // slots of W(step + 3) and of x pair (step + 5) >> 1
+        uint64_t ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
         if constexpr (ABL == 2) w4_stamp(ts0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NWS - 2) * NP) : "memory");      // tile step + 1 has landed (mine); the NWS - 2 groups behind it may fly
-        if constexpr (ABL == 2) w4_stamp(ts1);
-        UMV_BARRIER();                                                  // ... everyone's; and the slot of W tile `step` is free
-        if constexpr (ABL == 2) w4_stamp(ts2);
-        const int q = (step + 5) >> 1;                                  // the x pair this body stages half of
-        if constexpr (even) prep_x(q, std::integral_constant<int, 1>{});
-        else prep_x(q, std::integral_constant<int, 0>{});
-        prep_w(step + NWS);
-        const int sw = step % NWS, sx = q % 3;
-        const uint32_t wa = lds0 + ((step + 1) % NWS) * WSLOT + woff;
-        const uint32_t xa = lds0 + (((step + 1) >> 1) % 3) * XSLOT + (even ? xoff1 : xoff0);     // tile step + 1 is the odd half in an even body
         static_for<0, NMMA>([&](auto I) {
             constexpr int i = decltype(I)::value, t = i / TM, j = i % TM;
+            if constexpr (j == 0 && i < QB) {         // group t starts: W fragment t (and, for t = 0, every x fragment) has landed
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN - 1 - t) : "memory");
+                w4_touch(wc[t]);
+                if constexpr (t == 0) static_for<0, TM>([&](auto J) { w4_touch(xc[decltype(J)::value]); });
+            }
+            if constexpr (i == QB) {
+                if constexpr (ABL == 2) w4_stamp(ts1);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+                static_for<QB / TM, TN>([&](auto T) { w4_touch(wc[decltype(T)::value]); });
+                UMV_BARRIER();
+                if constexpr (ABL == 2) w4_stamp(ts2);
+            }
             w4_mfma<i>(wc[t], xc[j]);
-            constexpr int rd = umv_interleave_slot(i, NMMA, NRD);
-            if constexpr (rd >= 0 && rd < TN) w4_lds_read_frag<(rd < TN ? rd : 0) * 1024>(wnx[rd < TN ? rd : 0], wa);
-            else if constexpr (rd >= TN) w4_lds_read_frag<(rd >= TN ? rd - TN : 0) * 2048>(xnx[rd >= TN ? rd - TN : 0], xa);
-            constexpr int pc = umv_dma_slot(i, NMMA, NP);
-            if constexpr (pc >= 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (pc < XPB)
-                    __builtin_amdgcn_global_load_lds((const void*)px[pc < XPB ? pc : 0], (lds_ptr_w4_t)dstX(sx, (even ? XPB : 0) + pc), 16, 0, 0);
-                else
-                    __builtin_amdgcn_global_load_lds((const void*)pw[pc >= XPB ? pc - XPB : 0], (lds_ptr_w4_t)dstW(sw, pc - XPB), 16, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i >= QB) {
+                // behind the barrier: one filler every second MFMA - reads and pieces alternate until the pieces run out
+                constexpr int f = i - QB;             // filler slot
+                constexpr int NF = NRD + NP;
+                constexpr int span = NMMA - QB - 2;   // the last two MFMAs stay bare
+                constexpr int k = w4_filler_at(f, NF, span);      // filler k (0 .. NF-1) goes behind MFMA QB + k * span / NF
+                if constexpr (k >= 0) {
+                    // fillers 0, 2, 4 ... are reads while pieces remain (piece p is filler 2p + 1), then only reads
+                    constexpr bool is_piece = (k & 1) && (k / 2 < NP);
+                    if constexpr (is_piece) {
+                        constexpr int pc = k / 2;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (pc < XPB) stage_x((step + 5) >> 1, std::integral_constant<int, sx_stage>{}, std::integral_constant<int, even ? 1 : 0>{}, std::integral_constant<int, pc < XPB ? pc : 0>{});
+                        else stage_w(step + 3, std::integral_constant<int, sw_stage>{}, std::integral_constant<int, pc >= XPB ? pc - XPB : 0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        constexpr int rd = k < 2 * NP ? k / 2 : k - NP;
+                        read_frag(std::integral_constant<int, rd>{}, std::integral_constant<int, sw_next>{}, std::integral_constant<int, sx_next>{},
+                                  std::integral_constant<int, even ? 1 : 0>{}, wnx, xnx);      // tile step + 1 is the odd k half of its pair in an even body
+                    }
+                }
             }
         });
-        if constexpr (ABL == 2) w4_stamp(ts3);
-        land(wnx, xnx);
         if constexpr (ABL == 2) {
-            w4_stamp(ts4);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts0), "+s"(ts1), "+s"(ts2), "+s"(ts3), "+s"(ts4)::"memory");
+            w4_stamp(ts3);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts0), "+s"(ts1), "+s"(ts2), "+s"(ts3)::"memory");
             if (blockIdx.x < 8 && step >= 16 && step < 80 && lane == 0) {
                 uint64_t* tr = reinterpret_cast<uint64_t*>(const_cast<float*>(a.w_scale)) + (((int)blockIdx.x * NW + wave) * 64 + (step - 16)) * 5;
-                tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts4;
+                tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts3;
             }
         }
     };
-    for (int step = 0; step < nsteps; step += 2) {
-        body(std::true_type{}, step, wfA, xfA, wfB, xfB);
-        if (step + 1 < nsteps) body(std::false_type{}, step + 1, wfB, xfB, wfA, xfA);
+    for (int base = 0; base < nsteps; base += 6) {
+        body(std::integral_constant<int, 0>{}, base, wfA, xfA, wfB, xfB);
+        if (base + 1 >= nsteps) break;
+        body(std::integral_constant<int, 1>{}, base + 1, wfB, xfB, wfA, xfA);
+        if (base + 2 >= nsteps) break;
+        body(std::integral_constant<int, 2>{}, base + 2, wfA, xfA, wfB, xfB);
+        if (base + 3 >= nsteps) break;
+        body(std::integral_constant<int, 3>{}, base + 3, wfB, xfB, wfA, xfA);
+        if (base + 4 >= nsteps) break;
+        body(std::integral_constant<int, 4>{}, base + 4, wfA, xfA, wfB, xfB);
+        if (base + 5 >= nsteps) break;
+        body(std::integral_constant<int, 5>{}, base + 5, wfB, xfB, wfA, xfA);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> v_accvgpr_read wait states by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    UMV_BARRIER();      // every wave has read its last fragments: the staging buffers are free
+    UMV_BARRIER();      // every wave has read its last fragments and all pieces have landed: the staging buffers are free
 
     // epilogue: the accumulators leave the AGPRs 4 m-tiles at a time (TN x 4 x 4 = 128 registers at TN = 8) and go through the
     // wave's own LDS region as whole rows (gemm_epilogue.h); same arithmetic and roundings as the 8-wave tiles
@@ -252,40 +264,54 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
             });
         });
         epi_wave_tile_lds<TN, JC, false>(e, acc, wreg, lane, m0 + wm * TM * 16 + h * JC * 16, a.M, a.row_idx, nt_base, NTT,
-                                        BIAS_LDS ? bias_lds + wn * TN * 16 : nullptr);
+                                        bias_lds + wn * TN * 16);
     });
 }
 
-template <int WN, int WM, int TN, int TM, int NWS = 3, int ABL = 0>
+template <int WN, int WM, int TN, int TM, int ABL = 0>
 static int launch_w4(const umv_gemm_args& a, int KT, int NTT, int gn, hipStream_t s) {
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
-    constexpr size_t rings = (size_t)NWS * (BN / 16) * 1024 + (size_t)3 * BM * 128;
-    constexpr size_t lds = rings + BN * 2 <= 160 * 1024 ? rings + (BN * 2 + 15) / 16 * 16 : rings;
+    constexpr size_t lds = (size_t)3 * (BN / 16) * 1024 + (size_t)3 * BM * 128 + (BN * 2 + 15) / 16 * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((size_t)WN * WM * TN * 4 * 512 <= lds, "epilogue regions fit the staging area");
-    static bool attr_set[UMV_MAX_DEVICES] = {};
-    if (umv_first_on_device(attr_set)) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<WN, WM, TN, TM, NWS, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
     const int mblocks = (a.M + BM - 1) / BM, nblocks = (a.N + BN - 1) / BN;
     const int ms = umv_tile_superblock(mblocks, BM, a.K);
-    hipLaunchKernelGGL((gemm_w4_kernel<WN, WM, TN, TM, NWS, ABL>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks, nblocks, gn, ms);
+    auto go = [&](auto RAG) {
+        constexpr bool ragk = decltype(RAG)::value;
+        static bool attr_set[UMV_MAX_DEVICES] = {};
+        if (umv_first_on_device(attr_set))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<WN, WM, TN, TM, ABL, ragk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_w4_kernel<WN, WM, TN, TM, ABL, ragk>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks, nblocks, gn, ms);
+    };
+    if (a.K % 32) go(std::true_type{});
+    else go(std::false_type{});
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
 
-// cfg: 466 = 256(n) x 256(m), 468 = 256(n) x 128(m), 484 -> 4384 = 384(n) x 128(m); bf16 output, no split-K (the caller checks)
+// Shapes the 32-bit piece offsets can address: the packed weight image and every x row the call can touch lie within 2 GiB of
+// their base pointers (x_rows = rows of the buffer row_idx points into; unknown -> the caller keeps the 8-wave tiles)
+bool umv_gemm_w4_can_take(const umv_gemm_args& a, int KT, int NTT) {
+    if ((a.epilogue & UMV_EPI_OUT_F32) || a.k_splits > 1) return false;
+    if ((int64_t)NTT * KT * 1024 >= ((int64_t)1 << 31)) return false;
+    const int64_t rows = a.row_idx ? a.x_rows : (int64_t)a.M;
+    if (rows <= 0 || rows * a.ldx * 2 + 256 >= ((int64_t)1 << 31)) return false;
+    return true;
+}
+
+// cfg: 466 = 256(n) x 256(m), 468 = 256(n) x 128(m), 4384 = 384(n) x 128(m); bf16 output, no split-K (umv_gemm_w4_can_take)
 int umv_gemm_w4_launch(const umv_gemm_args& a, int KT, int NTT, int cfg, int gn, hipStream_t s) {
+    if (!umv_gemm_w4_can_take(a, KT, NTT)) {
+        umv_set_error("gemm_w4: shape / mode not addressable by the 4-wave tiles (fp32 output, K split, or operands beyond 2 GiB)");
+        return UMV_ERR_UNSUPPORTED;
+    }
     if (cfg == 466) return launch_w4<2, 2, 8, 8>(a, KT, NTT, gn, s);
-    if (cfg == 4664) return launch_w4<2, 2, 8, 8, 4>(a, KT, NTT, gn, s);          // W ring of 4 slots
-    if (cfg == 4684) return launch_w4<2, 2, 8, 4, 4>(a, KT, NTT, gn, s);
-#ifdef UMV_GEMM_ABLATIONS
-    if (cfg == 94661) return launch_w4<2, 2, 8, 8, 3, 1>(a, KT, NTT, gn, s);      // timing only: every piece an L2 hit
-    if (cfg == 94664) return launch_w4<2, 2, 8, 8, 4, 1>(a, KT, NTT, gn, s);
-    if (cfg == 94662) return launch_w4<2, 2, 8, 8, 3, 2>(a, KT, NTT, gn, s);      // s_memtime trace (a.w_scale = the log)
-#endif
     if (cfg == 468) return launch_w4<2, 2, 8, 4>(a, KT, NTT, gn, s);
     if (cfg == 4384) return launch_w4<2, 2, 12, 4>(a, KT, NTT, gn, s);
+#ifdef UMV_GEMM_ABLATIONS
+    if (cfg == 94661) return launch_w4<2, 2, 8, 8, 1>(a, KT, NTT, gn, s);      // timing only: every piece an L2 hit
+    if (cfg == 94662) return launch_w4<2, 2, 8, 8, 2>(a, KT, NTT, gn, s);      // s_memtime trace (a.w_scale = the log)
+#endif
     umv_set_error("gemm_w4: unknown tile configuration %d", cfg);
     return UMV_ERR_ARG;
 }

@@ -242,7 +242,8 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         out=out.data_ptr(), ldo=out.stride(0),
         row_idx=row_idx.data_ptr() if row_idx is not None else None,
         M=M, N=lin.N, K=lin.K, epilogue=flags,
-        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th, argmax_partial=amax)
+        norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th, argmax_partial=amax,
+        x_rows=x.shape[0])
     check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
     return out
 
