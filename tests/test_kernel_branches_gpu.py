@@ -196,7 +196,9 @@ def test_gemm_splitk_partials_sum_to_fp32_reference(ops, M, N, K, S):
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 100, 2048, 266), (515, 1000, 1152, 268), (1000, 4300, 1152, 266), (777, 250, 1024, 270),
                                           (515, 1000, 1160, 288), (130, 300, 3584, 288),    # 288 x 128: 26 staging pieces on 8 waves
-                                          (300, 100, 2048, -266), (777, 250, 1024, -270)])  # negative: the half-line staging (UMV_GEMM_XLINE=0)
+                                          (300, 100, 2048, -266), (777, 250, 1024, -270),   # negative: the half-line staging (UMV_GEMM_XLINE=0)
+                                          (300, 100, 2048, 466), (1000, 4300, 1152, 466), (515, 1000, 1160, 468), (130, 300, 3584, 4384),
+                                          (260, 520, 40, 466)])                             # the 4-wave AGPR tiles (gemm_w4.hip), K shorter than their prologue
 def test_gemm_lds_epilogue_ragged_and_unaligned(ops, M, N, K, tile, monkeypatch):
     """The whole-row LDS epilogue of the tiled kernels (gemm_epilogue.h::epi_wave_tile_lds) on everything that leaves its 16-byte
     fast path: N not a multiple of 8 (the last 16-byte chunk of a row is partial), an output / residual row pitch that is not a
@@ -275,6 +277,45 @@ print('sha swiglu', hashlib.sha256(o3.cpu().view(torch.int16).numpy().tobytes())
         shas[xl] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
         assert len(shas[xl]) == 17
     assert shas["0"] == shas["1"], [(a, b) for a, b in zip(shas["0"], shas["1"]) if a != b]
+
+
+@pytest.mark.parametrize("tile", [266, 268, 384])
+def test_gemm_w4_bit_identical(ops, tile):
+    """The 4-wave tiles with the accumulators in literal AGPRs (gemm_w4.hip: 256 x 256, 256 x 128, 384 x 128; the default for
+    K >= 2048, UMV_GEMM_W4=2 forces them at every K) against the 8-wave tiles of the same shape (UMV_GEMM_W4=0): the same MFMAs on
+    the same operands in the same k order, so every output bit must agree - full tiles, ragged M / N, K % 64 != 0 and K % 32 != 0
+    (zero-filled tail chunks), an odd number of k-steps, K shorter than the prologue, fewer k-steps than the unroll period, row-indexed
+    A / C, bias + residual, bias + GELU and the SwiGLU epilogue."""
+    import subprocess as sp
+    code = f"""
+import hashlib, sys, math, torch
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+from unimedvl_amd import ops
+from test_kernel_branches_gpu import rnd, BF16
+def sha(t): return hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+for M, N, K in ((2048, 4608, 3584), (8192, 1152, 4304), (1000, 1152, 1160), (300, 520, 1096), (700, 3584, 96), (515, 1152, 4304), (260, 300, 40), (4099, 777, 2080), (130, 260, 160)):
+    x = rnd((M, K), 1); w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
+    lin = ops.PackedLinear.from_weight(w, b)
+    res = rnd((M, N), 4)
+    print('sha', M, N, K, sha(ops.gemm(x, lin, residual=res)))
+    print('sha gelu', M, N, K, sha(ops.gemm(x, lin, act='gelu_tanh')))
+    T = M + 9
+    rows = torch.randperm(T, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))[:M].sort().values.to(torch.int32)
+    xs = torch.zeros((T, K), dtype=BF16, device='cuda'); xs[rows.long()] = x
+    o2 = torch.zeros((T, N), dtype=BF16, device='cuda')
+    ops.gemm(xs, lin, out=o2, M=M, row_idx=rows)
+    print('sha rows', M, N, K, sha(o2))
+g, u = rnd((1024, 2048), 6, 0.02), rnd((1024, 2048), 7, 0.02)
+lin = ops.PackedLinear.from_gate_up(g, u)
+print('sha swiglu', sha(ops.gemm(rnd((2050, 2048), 8), lin)))
+"""
+    shas = {}
+    for w4 in ("0", "2"):
+        r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, UMV_GEMM_TILE=str(tile), UMV_GEMM_W4=w4))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        shas[w4] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
+        assert len(shas[w4]) == 28
+    assert shas["0"] == shas["2"], [(a, b) for a, b in zip(shas["0"], shas["2"]) if a != b]
 
 
 def test_skinny_full_line_x_staging_bit_identical(ops):

@@ -10,7 +10,7 @@
 set -e
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--no-cpu-baseline --no-t2i --no-fp8 --no-report --no-vit --no-load-path"
+ARGS="--no-cpu-baseline --no-t2i --no-fp8 --no-report --no-vit --no-load-path --no-sampled"
 mkdir -p gpurun_out/$TAG/trace gpurun_out/$TAG/FETCH_SIZE gpurun_out/$TAG/WRITE_SIZE
 rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/trace -o bench -- python bench.py $ARGS --steps 512 --warmup 8 > gpurun_out/$TAG/trace/bench.log 2>&1 || true
 grep '^{' gpurun_out/$TAG/trace/bench.log > gpurun_out/${TAG}_decode_line_under_rocprof.json || true
@@ -22,11 +22,11 @@ done
 # MFMA-bound legs: counters of the dominant kernels of the ViT tower, the image-span prefill and the text-to-image leg
 # (one rocprofv3 pass per counter set, --kernel-trace only), attached by bench.py to its vit_encode / t2i objects
 if [ -z "$SKIP_STAGE_PMC" ]; then
-for ST in vit prefill t2i; do
+for ST in vit prefill t2i edit; do
   for C in "MfmaUtil" "LdsUtil" "SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"; do
     D=gpurun_out/$TAG/stage_${ST}_$(echo $C | tr ' ' '_')
     mkdir -p $D
-    REPS=3 rocprofv3 --pmc $C --kernel-trace -d $D -o pmc -- python tools/stage_profile.py $ST > $D/log.txt 2>&1 || true
+    REPS=3 STEPS=12 rocprofv3 --pmc $C --kernel-trace -d $D -o pmc -- python tools/stage_profile.py $ST > $D/log.txt 2>&1 || true
   done
 done
 fi
@@ -34,7 +34,7 @@ python - <<PY
 import csv, glob, json, sqlite3
 tag = "$TAG"
 stage_pmc = {}
-for st in ("vit", "prefill", "t2i"):
+for st in ("vit", "prefill", "t2i", "edit"):
     rows = {}
     for d in glob.glob(f"gpurun_out/{tag}/stage_{st}_*"):
         dbs = glob.glob(d + "/*results.db")
@@ -43,7 +43,7 @@ for st in ("vit", "prefill", "t2i"):
         cur = sqlite3.connect(dbs[0]).cursor()
         q = """select s.kernel_name, c.name, count(*), avg(p.value) from rocpd_pmc_event p
                join rocpd_kernel_dispatch d on p.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-               join rocpd_info_pmc c on p.pmc_id = c.id where s.kernel_name like '%gemm_tiled%' or s.kernel_name like '%attn_prefill%'
+               join rocpd_info_pmc c on p.pmc_id = c.id where s.kernel_name like '%gemm_tiled%' or s.kernel_name like '%gemm_w4%' or s.kernel_name like '%attn_prefill%'
                group by 1, 2"""
         try:
             for name, cname, n, avg in cur.execute(q):

@@ -3,6 +3,7 @@
     python tools/stage_profile.py vit [B]        ViT tower + connector on B 448x448 images
     python tools/stage_profile.py prefill [B]    forward_cache_update_vit + forward_cache_update_text (image span + question)
     python tools/stage_profile.py t2i [B]        bench.run_t2i: 50 guided flow steps at 256x256 + VAE decode (one timed run)
+    python tools/stage_profile.py edit [B]       bench.run_edit: 448x448 -> 512x512 edit flow over three distinct contexts (STEPS timesteps)
 Prints the wall time per repetition; under `rocprofv3 --kernel-trace --stats` the per-kernel table is that stage's alone
 (plus the one-time weight initialisation, which only uses torch / pack kernels)."""
 import os
@@ -12,7 +13,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from bench import IdTokenizer, run_t2i, synth_image  # noqa: E402
+from bench import IdTokenizer, run_edit, run_t2i, synth_image  # noqa: E402
 from unimedvl_amd.bagel import Bagel  # noqa: E402
 from unimedvl_amd.config import UniMedVLConfig  # noqa: E402
 from unimedvl_amd.kvcache import NaiveCache  # noqa: E402
@@ -47,10 +48,14 @@ def main():
     cfg.llm_weight_dtype = os.environ.get("WEIGHTS", "bf16")
     if os.environ.get("ACT8", "0") != "0":
         cfg.llm_act_dtype = "fp8"
-    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=stage == "t2i", visual_und=True)
+    model = Bagel(cfg, random_getter(cfg, dev, seed=1234), device=dev, visual_gen=stage in ("t2i", "edit"), visual_und=True)
     if stage == "t2i":
         r = run_t2i(model, cfg, dev, 0, 1, None, batch=B if len(sys.argv) > 2 else 4)
         print(f"t2i: {r['s_per_batch'] * 1e3:.3f} ms per repetition (1 reps) {r['images_per_s']} images/s {r['llm_tflops']} TF/s")
+        return
+    if stage == "edit":
+        r = run_edit(model, cfg, dev, 0, 1, None, batch=B if len(sys.argv) > 2 else 4, num_timesteps=int(os.environ.get("STEPS", "50")))
+        print(f"edit: {r['s_per_batch'] * 1e3:.3f} ms per repetition (1 reps) {r['images_per_s']} images/s {r['llm_tflops']} TF/s, context build {r['context_build_s']} s")
         return
     ids = dict(bos_token_id=cfg.vocab - 4, eos_token_id=cfg.vocab - 3, start_of_image=cfg.vocab - 2, end_of_image=cfg.vocab - 1)
     images = [synth_image(448, 448, i) for i in range(B)]

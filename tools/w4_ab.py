@@ -54,22 +54,22 @@ def main():
     if "sha" in what:
         for tile in ("266", "268", "384"):
             shas = {}
-            for w4 in ("0", "1"):
+            for w4 in ("0", "2"):
                 r = run([sys.executable, "-c", SHA_CODE], {"UMV_GEMM_TILE": tile, "UMV_GEMM_W4": w4})
                 if r.returncode != 0:
                     print(f"tile {tile} w4={w4} FAILED rc={r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}", flush=True)
                     shas[w4] = None
                     continue
                 shas[w4] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
-            if shas.get("0") and shas.get("1"):
-                bad = [(a, b) for a, b in zip(shas["0"], shas["1"]) if a != b]
+            if shas.get("0") and shas.get("2"):
+                bad = [(a, b) for a, b in zip(shas["0"], shas["2"]) if a != b]
                 print(f"tile {tile}: {len(shas['0'])} outputs, {'BIT-IDENTICAL' if not bad else f'{len(bad)} DIFFER'}", flush=True)
                 for a, b in bad[:12]:
                     print("   8-wave", a, "| 4-wave", b, flush=True)
     if "time" in what:
         shapes = os.environ.get("SHAPES", ";".join(TIME_SHAPES)).split(";")
         for shape in shapes:
-            for w4 in ("0", "1"):
+            for w4 in os.environ.get("W4_ARMS", "0,2").split(","):
                 r = run([sys.executable, os.path.join(ROOT, "tools", "gemm_power.py")], {"UMV_GEMM_W4": w4, "SHAPE": shape, "SECONDS": secs})
                 line = (r.stdout.strip().splitlines() or [r.stderr[-400:]])[-1]
                 print(f"w4={w4} {line}", flush=True)

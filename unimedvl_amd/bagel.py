@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .config import UniMedVLConfig
-from .data_utils import (get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
+from .data_utils import (PackedVitImages, get_flattened_position_ids_extrapolate, get_flattened_position_ids_interpolate, patchify)
 from .decode import DecodeSession
 from .prep import BagelPrep
 from .kvcache import NaiveCache
@@ -123,8 +123,10 @@ class Bagel(BagelPrep):
         # only be replayed on storage laid out exactly like the one it was captured on (a new cache that happens to reuse the
         # layer-0 address alone must not match - it would be written through stale addresses for the other layers)
         slabs = tuple(p for sl in cache.slabs for p in (sl.k.data_ptr(), sl.vt.data_ptr()))
+        # ... and the input kind: a plan made for images (device patchify) cannot be refreshed from a patch tensor or the reverse
+        kind = "images" if isinstance(gi["packed_vit_tokens"], PackedVitImages) else "tokens"
         return (slabs, cache.cap, len(cache.lens), lens[0], int(pos[0]), int(pos[-1]), int(gi["packed_text_ids"][0]),
-                int(gi["packed_text_ids"][-1]))
+                int(gi["packed_text_ids"][-1]), kind)
 
     def _vit_graph_run(self, key, cache, gi):
         dev, lm = self.device, self.language_model

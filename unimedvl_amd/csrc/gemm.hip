@@ -1623,12 +1623,18 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (xline < 0) { const char* e = getenv("UMV_GEMM_XLINE"); xline = e ? atoi(e) : 1; }      // (2: also the 288-column tile, under evaluation)
         if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : (cfg == 288 && xline > 1) ? 388 : cfg;
     }
-    {   // round 5: the 4-wave tiles with the accumulators in AGPRs (gemm_w4.hip) take over the 8-wave tiles of the same shape;
-        // bit-identical results (same MFMAs, operands and k order).  UMV_GEMM_W4=0: the 8-wave tiles (A/B, tuning only)
+    {   // round 5: the 4-wave tiles with the accumulators in AGPRs (gemm_w4.hip) take over the 8-wave tiles of the same shape on the
+        // LLM's GEMMs (K = 3584 / 18944): bit-identical results (same MFMAs, operands and k order), sustained loops on MI355X
+        // (profiles/r05_w4_policy.txt): gate/up 2048 x 37888 x 3584 458 -> 408 us (1.21 -> 1.36 PF), 8208 rows 1790 -> 1602 us (1.39 PF),
+        // down 2048 x 3584 x 18944 254 -> 205 us (1.36 PF), o_proj 8208 x 3584 x 3584 182 -> 169 us; end to end text-to-image
+        // 1387 -> 1315 ms per batch of 4, prefill of 8 images 123.1 -> 116.5 ms.  NOT at short K: a 256 x 256 tile's fill and its
+        // 256-register epilogue on four waves cost more than the 8-wave tile's at K = 1152 (SigLIP q/k/v 67.8 -> 80.6 us, fc1
+        // 85.8 -> 103.4 us, tower 11.6 -> 12.3 ms with the 4-wave tiles everywhere), so the rule is K >= 2048.
+        // UMV_GEMM_W4=0: the 8-wave tiles everywhere, 2: the 4-wave tiles at every K (A/B, tuning only)
         static int w4 = -1;
-        if (w4 < 0) { const char* e = getenv("UMV_GEMM_W4"); w4 = e ? atoi(e) : 0; }
+        if (w4 < 0) { const char* e = getenv("UMV_GEMM_W4"); w4 = e ? atoi(e) : 1; }
         const int c4 = cfg == 366 ? 466 : cfg == 368 ? 468 : cfg == 484 ? 4384 : 0;
-        if (w4 && c4 && (w4 == 1 || w4 == c4) && umv_gemm_w4_can_take(a, KT, NTT)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
+        if (w4 && c4 && (w4 == 2 || a.K >= 2048) && umv_gemm_w4_can_take(a, KT, NTT)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
     }
     if (cfg == 466 || cfg == 468 || cfg == 4384 || cfg == 94661 || cfg == 94662) return umv_gemm_w4_launch(a, KT, NTT, cfg, raster_gn(), s);
     // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)

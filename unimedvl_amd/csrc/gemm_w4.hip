@@ -83,6 +83,8 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int wn = wave % WN, wm = wave / WN;
+    uint64_t tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0, tw4 = 0;       // ABL = 2: tile-level stamps (entry, first body, loop end, first epilogue chunk, end)
+    if constexpr (ABL == 2) w4_stamp(tw0);
     // the accumulators: a[0 : NACC-1] = 0 (the clobber list is what tells the compiler that this kernel owns AGPRs at all)
     asm volatile("" ::: "a0", "a255");
     static_for<0, NACC>([&](auto I) {
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * XPB + 2 * WPW) : "memory");      // x pair 0 and W(0) landed; what was issued behind them may fly
     UMV_BARRIER();
     static_for<0, NRD>([&](auto RD) { read_frag(RD, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, wfA, xfA); });
+    if constexpr (ABL == 2) w4_stamp(tw1);
 
     // body U (compile time: position in the period of 6) of k-step `step`
     auto body = [&](auto UC, int step, bf16x8(&wc)[TN], bf16x8(&xc)[TM], bf16x8(&wnx)[TN], bf16x8(&xnx)[TM]) {
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
     // the MFMAs are opaque to the compiler's hazard recogniser: cover the XDL-write -> v_accvgpr_read wait states by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     UMV_BARRIER();      // every wave has read its last fragments and all pieces have landed: the staging buffers are free
+    if constexpr (ABL == 2) w4_stamp(tw2);
 
     // epilogue: the accumulators leave the AGPRs 4 m-tiles at a time (TN x 4 x 4 = 128 registers at TN = 8) and go through the
     // wave's own LDS region as whole rows (gemm_epilogue.h); same arithmetic and roundings as the 8-wave tiles
@@ -265,7 +269,22 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
         });
         epi_wave_tile_lds<TN, JC, false>(e, acc, wreg, lane, m0 + wm * TM * 16 + h * JC * 16, a.M, a.row_idx, nt_base, NTT,
                                         bias_lds + wn * TN * 16);
+        if constexpr (ABL == 2 && h == 0) w4_stamp(tw3);
     });
+    if constexpr (ABL == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores of this wave have been accepted
+        w4_stamp(tw4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tw0), "+s"(tw1), "+s"(tw2), "+s"(tw3), "+s"(tw4)::"memory");
+        // tile-level log behind the k-step log (8 x NW x 64 x 5 words): 6 words per wave of the first 64 workgroups and of the last 64
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        const int slot = b < 64 ? b : (b >= nb - 64 ? 64 + (b - (nb - 64)) : -1);
+        if (slot >= 0 && lane == 0) {
+            uint64_t* tr = reinterpret_cast<uint64_t*>(const_cast<float*>(a.w_scale)) + 8 * NW * 64 * 5 + (slot * NW + wave) * 6;
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            tr[0] = tw0; tr[1] = tw1; tr[2] = tw2; tr[3] = tw3; tr[4] = tw4; tr[5] = hw;
+        }
+    }
 }
 
 template <int WN, int WM, int TN, int TM, int ABL = 0>

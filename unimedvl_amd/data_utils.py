@@ -26,9 +26,23 @@ class PackedVitImages:
         self._tokens = None
 
     def tokens(self):
+        """The reference's packed patch tensor, made where the images live and in their dtype - so `.to("cuda")` followed by a
+        torch function behaves like the move of a tensor would (same device, same dtype as the reference's result)."""
         if self._tokens is None:
-            self._tokens = torch.cat([patchify(im.to(torch.float32).cpu() if im.is_cuda else im, self.patch_size) for im in self.images], dim=0)
+            self._tokens = torch.cat([patchify(im, self.patch_size) for im in self.images], dim=0)
         return self._tokens
+
+    @property
+    def device(self):
+        return self.images[0].device if self.images else torch.device("cpu")
+
+    @property
+    def dtype(self):
+        return self.images[0].dtype if self.images else torch.float32
+
+    @property
+    def is_cuda(self):
+        return self.device.type == "cuda"
 
     def token_counts(self):
         p = self.patch_size
