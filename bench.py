@@ -53,9 +53,9 @@ def _tiled_normal(shape, base):
     return base.repeat((n + base.numel() - 1) // base.numel())[:n].view(shape)
 
 
-def cpu_baseline(batch, ctx, full_layers, seed=1234):
-    """Oracle (CPU restatement of the reference) timed on the host cores: full-width decode step,
-    2 of 28 layers + lm_head, scaled linearly to full depth.  Reported baseline, not a target."""
+def _cpu_decode_measure(batch, ctx, full_layers, seed=1234, reps=15):
+    """(child process of cpu_baseline) the oracle's full-width decode step on the threads this process was started with:
+    2 of `full_layers` layers + lm_head, sorted per-repetition times"""
     from oracle.unimedvl_cpu import OracleBagel, KVCache
     from oracle.weights import FULL, llm_shapes
     c = dict(FULL)
@@ -87,9 +87,7 @@ def cpu_baseline(batch, ctx, full_layers, seed=1234):
         for l in range(2):
             for s in range(batch):
                 cache.k[l][s] = cache.k[l][s][:ctx]; cache.v[l][s] = cache.v[l][s][:ctx]
-    reps = 15
-
-    def measure():
+    with torch.no_grad():
         for _ in range(3):                    # warm-up: first touch of the weights, oneDNN primitive cache
             h = layers_only()
             trim()
@@ -105,13 +103,34 @@ def cpu_baseline(batch, ctx, full_layers, seed=1234):
             lg = o.lm_head(h)
             torch.argmax(lg, -1)
             th.append(time.perf_counter() - t0)
-        tl.sort(); th.sort()
-        return tl, th
-    # M = 8 rows is a string of small ops: on a many-core host the default thread count (all logical CPUs) is slower than a
-    # moderate one.  Two pinned figures are reported: 32 threads on 32 physical cores of ONE socket (the configuration that was
-    # fastest on the 2 x 64-core box) and one thread per physical core of the whole host; `value` is the faster of the two.
-    # The affinity mask is what makes the number repeat between runs (unpinned, the same leg moved 4x between two boxes of one class).
-    default_threads = torch.get_num_threads()
+    tl.sort(); th.sort()
+    return tl, th
+
+
+def cpu_child_main(spec):
+    """`python bench.py --cpu-child '<json>'`: one arm of the CPU baseline in a process of its own.  The parent has set the
+    affinity mask and the OpenMP environment BEFORE this interpreter started, so torch's thread pool is born pinned (setting the
+    mask from inside a process that already ran torch ops only moves the calling thread - the same leg then wandered 4x)."""
+    torch.set_num_threads(int(spec["threads"]))
+    tl, th = _cpu_decode_measure(spec["batch"], spec["ctx"], spec["layers"])
+    out = {"tl": tl, "th": th}
+    if spec.get("vision"):
+        try:
+            out["vision"] = cpu_baseline_vision(spec["layers"], spec["vit_layers"])
+        except Exception as e:
+            out["vision_failed"] = f"{type(e).__name__}: {e}"
+    print("CPU_CHILD_RESULT " + json.dumps(out), flush=True)
+
+
+def cpu_baseline(batch, ctx, full_layers, full_vit_layers, vision=True):
+    """Oracle (CPU restatement of the reference) timed on the host cores: full-width decode step, 2 of 28 layers + lm_head, scaled
+    linearly to full depth (+ the ViT / T2I / edit legs of cpu_baseline_vision).  Reported baseline, not a target.
+
+    M = 8 rows is a string of small ops: on a many-core host the default thread count (all logical CPUs) is slower than a moderate
+    one.  Two PINNED figures are reported, each from a fresh process started under its affinity mask (one OpenMP thread per
+    physical core, OMP_PROC_BIND=close): 32 cores of ONE socket - fastest on the 2 x 64-core box - and every physical core of
+    the host; `value` is the faster of the two, `runs` carries both with the spread of their 15 repetitions."""
+    import subprocess
     aff0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     topo = _cpu_topology()
     arms = []
@@ -119,36 +138,51 @@ def cpu_baseline(batch, ctx, full_layers, seed=1234):
         sock0 = sorted(c for c in topo[sorted(topo)[0]] if c in aff0)
         allphys = sorted(c for cs in topo.values() for c in cs if c in aff0)
         if sock0:
-            arms.append(("one socket, %d physical cores" % min(32, len(sock0)), set(sock0[:32]), min(32, len(sock0))))
+            arms.append(("one socket, %d physical cores" % min(32, len(sock0)), sorted(sock0[:32]), min(32, len(sock0))))
         if len(allphys) > 32:
-            arms.append(("all %d physical cores" % len(allphys), set(allphys), len(allphys)))
+            arms.append(("all %d physical cores" % len(allphys), allphys, len(allphys)))
     if not arms:
-        arms.append(("unpinned", None, min(default_threads, 32)))
-    runs = []
-    with torch.no_grad():
-        for label, mask, nt in arms:
-            try:
-                if mask is not None:
-                    os.sched_setaffinity(0, mask)
-                torch.set_num_threads(nt)
-                tl, th = measure()
-            finally:
-                if aff0 is not None:
-                    os.sched_setaffinity(0, aff0)
-            med = tl[reps // 2] / 2 * full_layers + th[reps // 2]
-            lo = tl[1] / 2 * full_layers + th[1]
-            hi = tl[-2] / 2 * full_layers + th[-2]
-            runs.append({"pinning": label, "threads": nt, "tokens_per_s": round(batch / med, 3),
-                         "spread_tokens_per_s": [round(batch / hi, 3), round(batch / lo, 3)],
-                         "ms_per_layer": round(tl[reps // 2] / 2 * 1e3, 2), "ms_head": round(th[reps // 2] * 1e3, 2), "step_s": med})
-    torch.set_num_threads(default_threads)
-    best = min(runs, key=lambda r: r["step_s"])
-    for r in runs:
+        arms.append(("unpinned", None, min(torch.get_num_threads(), 32)))
+    reps = 15
+    runs, vis = [], {}
+    for i, (label, cpus, nt) in enumerate(arms):
+        spec = dict(threads=nt, batch=batch, ctx=ctx, layers=full_layers, vit_layers=full_vit_layers, vision=bool(vision and i == 0))
+        env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt), OMP_PROC_BIND="close", OMP_PLACES="cores",
+                   HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        pre = (lambda m=set(cpus): os.sched_setaffinity(0, m)) if cpus is not None else None
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(spec)], env=env, preexec_fn=pre,
+                               capture_output=True, text=True, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("CPU_CHILD_RESULT ")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError(f"child rc={r.returncode}: {r.stderr[-400:]}")
+            res = json.loads(line[-1][len("CPU_CHILD_RESULT "):])
+        except Exception as e:
+            runs.append({"pinning": label, "threads": nt, "failed": f"{type(e).__name__}: {e}"})
+            continue
+        tl, th = res["tl"], res["th"]
+        med = tl[reps // 2] / 2 * full_layers + th[reps // 2]
+        lo = tl[1] / 2 * full_layers + th[1]
+        hi = tl[-2] / 2 * full_layers + th[-2]
+        runs.append({"pinning": label, "threads": nt, "tokens_per_s": round(batch / med, 3),
+                     "spread_tokens_per_s": [round(batch / hi, 3), round(batch / lo, 3)],
+                     "ms_per_layer": round(tl[reps // 2] / 2 * 1e3, 2), "ms_head": round(th[reps // 2] * 1e3, 2), "step_s": med})
+        if "vision" in res:
+            vis = res["vision"]
+        elif "vision_failed" in res:
+            vis = {"vision_failed": res["vision_failed"]}
+    good = [r for r in runs if "step_s" in r]
+    if not good:
+        raise RuntimeError("; ".join(r.get("failed", "?") for r in runs))
+    best = min(good, key=lambda r: r["step_s"])
+    for r in good:
         r.pop("step_s")
-    return {
+    out = {
         "value": best["tokens_per_s"], "unit": "tokens/s", "cores": best["threads"], "kind": "port",
         "sample": f"oracle/unimedvl_cpu.py decode step, full width, 2 of {full_layers} layers + lm_head, B={batch}, "
-                  f"ctx={ctx}, median of {reps} after 3 warm-up steps, threads pinned ({best['pinning']}); per-layer time x{full_layers} + head "
+                  f"ctx={ctx}, median of {reps} after 3 warm-up steps, fresh process pinned to {best['pinning']}; per-layer time x{full_layers} + head "
                   f"({best['ms_per_layer']:.1f} ms/layer, {best['ms_head']:.1f} ms head)",
         "runs": runs,
         # the reference itself, timed in the build container against this port on the same inputs, needs
@@ -156,6 +190,8 @@ def cpu_baseline(batch, ctx, full_layers, seed=1234):
         "port_over_reference_time": 0.73,
         "reference_estimate_tokens_per_s": round(best["tokens_per_s"] * 0.73, 3),
     }
+    out.update(vis)
+    return out
 
 
 def _cpu_topology():
@@ -287,6 +323,36 @@ def _cpu_vision_legs(o, c, ntid, g, full_layers, full_vit_layers, out):
                       "sample": f"oracle text-to-image, one 256x256 image: 6 gen-mode passes of 258 tokens at 2 of {full_layers} layers "
                                 f"({t_pass2 / 2 * 1e3:.1f} ms/pass/layer) scaled to the reference's 131 passes x {full_layers} layers, "
                                 f"+ one full VAE decode ({t_vae:.2f} s); 50 timesteps, cfg 4.0 / 1.5"}
+        # ---- edit pipeline (interactive_image_generator.py cell 4): ONE 448x448 -> 512x512 request, three distinct contexts
+        try:
+            t0 = time.perf_counter()
+            img_vit = synth_image(448, 448, 2)
+            img_vae = torch.nn.functional.interpolate(img_vit[None], size=(512, 512), mode="bicubic", align_corners=False)[0].clamp(-1, 1).contiguous()
+            og = KVCache(2, 1)
+            ids = [[ntid["bos_token_id"]] + torch.randint(100, 2000, (32,), generator=g).tolist() + [ntid["eos_token_id"]]]
+            kv, rp = o.update_vae(og, [0], [0], [img_vae], ntid)
+            kv, rp = o.update_vit(og, kv, rp, [img_vit], ntid)
+            ot, rp_t = og.clone(), list(rp)
+            kv, rp = o.update_text(og, kv, rp, ids)
+            oi = KVCache(2, 1)
+            _, rp_i = o.update_text(oi, [0], [0], ids)
+            t_ctx2 = time.perf_counter() - t0                              # VAE encode + ViT (2 layers) + LLM prefills (2 layers)
+            noise = torch.randn(1024, 64, generator=g)
+            kw = dict(num_timesteps=2, timestep_shift=3.0, cfg_interval=(0.0, 1.0), cfg_text_scale=4.0, cfg_text=(ot, rp_t),
+                      cfg_img_scale=2.0, cfg_img=(oi, rp_i), cfg_renorm_type="text_channel")
+            t0 = time.perf_counter()
+            lat = o.generate_image(og, rp, [(512, 512)], noise, ntid, **kw)      # ONE guided step = 3 passes of 1026 tokens over 2 layers
+            t_pass2e = (time.perf_counter() - t0) / 3
+            t0 = time.perf_counter()
+            o.decode_image(lat[0], (512, 512))
+            t_vae512 = time.perf_counter() - t0
+            t_edit = 147 * (t_pass2e / 2 * full_layers) + t_vae512
+            out["edit"] = {"value": round(1.0 / t_edit, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"oracle edit flow, one 448x448 -> 512x512 request: 3 gen-mode passes of 1026 tokens at 2 of {full_layers} layers "
+                                     f"({t_pass2e / 2 * 1e3:.1f} ms/pass/layer, cold: one step, no warm-up) scaled to 147 passes x {full_layers} layers, + one "
+                                     f"full VAE decode at 512x512 ({t_vae512:.2f} s); context build (VAE encode + 2-layer ViT / prefills) {t_ctx2:.2f} s, not included"}
+        except Exception as e:      # the newest leg must not take the ViT / T2I baselines down with it
+            out["edit"] = {"value": None, "unit": "images/s", "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     return out
 
 
@@ -694,7 +760,10 @@ def main():
                          "[B, vocab] bf16 logits of every step")
     ap.add_argument("--fp8-act", type=int, default=1, help="fp8 leg: 1 = W8A8 (e4m3 activations on the fp8 MFMA) for prefill / flow "
                     "passes, 0 = bf16 activations on the bf16 image of the dequantised weights")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)      # internal: one pinned arm of the CPU baseline
     args = ap.parse_args()
+    if args.cpu_child:
+        return cpu_child_main(json.loads(args.cpu_child))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1185,15 +1254,11 @@ def main():
             out["load_path"] = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
         try:
-            out["cpu_baseline"] = cpu_baseline(B, ctx, cfg.layers)
+            out["cpu_baseline"] = cpu_baseline(B, ctx, cfg.layers, cfg.vit_layers)
         except Exception as e:  # the baseline leg must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
         out["cpu_baseline"]["host"] = cpu_info()
-        try:
-            out["cpu_baseline"].update(cpu_baseline_vision(cfg.layers, cfg.vit_layers))
-        except Exception as e:
-            out["cpu_baseline"]["vision_failed"] = f"{type(e).__name__}: {e}"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

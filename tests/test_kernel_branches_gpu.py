@@ -318,6 +318,63 @@ print('sha swiglu', sha(ops.gemm(rnd((2050, 2048), 8), lin)))
     assert shas["0"] == shas["2"], [(a, b) for a, b in zip(shas["0"], shas["2"]) if a != b]
 
 
+_EPI_SHA_CODE = """
+import hashlib, sys, math, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from unimedvl_amd import ops
+from test_kernel_branches_gpu import rnd, BF16
+def sha(t): return hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+for M, N, K in ((2048, 4608, 3584), (1000, 1152, 1160), (300, 520, 1096), (700, 3584, 96), (515, 1152, 2080), (260, 300, 40), (4099, 776, 2080), (130, 264, 160)):
+    x = rnd((M, K), 1); w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
+    lin, lin_nb = ops.PackedLinear.from_weight(w, b), ops.PackedLinear.from_weight(w)
+    res = rnd((M, N), 4)
+    print('sha plain', M, N, K, sha(ops.gemm(x, lin_nb)))
+    print('sha bias', M, N, K, sha(ops.gemm(x, lin)))
+    print('sha bias+res', M, N, K, sha(ops.gemm(x, lin, residual=res)))
+    print('sha res', M, N, K, sha(ops.gemm(x, lin_nb, residual=res)))
+    print('sha gelu', M, N, K, sha(ops.gemm(x, lin, act='gelu_tanh')))
+    T = M + 9
+    rows = torch.randperm(T, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))[:M].sort().values.to(torch.int32)
+    xs = torch.zeros((T, K), dtype=BF16, device='cuda'); xs[rows.long()] = x
+    o2 = torch.full((T, N), 3.0, dtype=BF16, device='cuda')
+    rs = rnd((T, N), 9)
+    ops.gemm(xs, lin, out=o2, M=M, row_idx=rows, residual=rs)
+    print('sha rows bias+res', M, N, K, sha(o2))
+    o3 = torch.full((T, N + 8), 5.0, dtype=BF16, device='cuda')       # output rows wider than N: columns N.. must stay untouched
+    ops.gemm(xs, lin_nb, out=o3[:, :N], M=M, row_idx=rows)
+    print('sha rows pitched', M, N, K, sha(o3))
+for I, K, M in ((1024, 2048, 2050), (520, 1152, 300)):
+    g, u = rnd((I, K), 6, 0.02), rnd((I, K), 7, 0.02)
+    lin = ops.PackedLinear.from_gate_up(g, u)
+    x = rnd((M, K), 8)
+    print('sha swiglu', I, K, M, sha(ops.gemm(x, lin)))
+    rows = torch.arange(0, 2 * M, 2, device='cuda', dtype=torch.int32)
+    xs = torch.zeros((2 * M, K), dtype=BF16, device='cuda'); xs[rows.long()] = x
+    o = torch.full((2 * M, I), 2.0, dtype=BF16, device='cuda')
+    ops.gemm(xs, lin, out=o, M=M, row_idx=rows)
+    print('sha swiglu rows', I, K, M, sha(o))
+"""
+
+
+@pytest.mark.parametrize("tile,w4", [(266, 0), (268, 0), (384, 0), (270, 0), (288, 0), (64, 0), (266, 2), (268, 2), (384, 2)])
+def test_gemm_lean_epilogue_bit_identical(ops, tile, w4):
+    """The branch-free epilogue of the tiled GEMMs (gemm_epilogue.h::epi_wave_tile_lean: flag combination at compile time, rows beyond
+    M / chunks beyond N dropped by the buffer range check, default) against the general one (UMV_GEMM_LEAN_EPI=0), on every tile
+    family of the policy, 8-wave and 4-wave: plain, bias, bias + residual, residual, bias + GELU, SwiGLU, row-indexed outputs (with a
+    residual; with an output pitch wider than N), ragged M and N, and shapes the lean form must decline (N % 8 != 0) - every output
+    bit, including the untouched rows / columns of the destination, must agree."""
+    import subprocess as sp
+    code = _EPI_SHA_CODE.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
+    shas = {}
+    for lean in ("0", "1"):
+        r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                   env=dict(os.environ, UMV_GEMM_TILE=str(tile), UMV_GEMM_W4=str(w4), UMV_GEMM_LEAN_EPI=lean))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        shas[lean] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
+        assert len(shas[lean]) == 8 * 7 + 4
+    assert shas["0"] == shas["1"], [(a, b) for a, b in zip(shas["0"], shas["1"]) if a != b]
+
+
 def test_skinny_full_line_x_staging_bit_identical(ops):
     """The weight-streaming kernels with x in full 128-byte lines (gemm.hip XL, the default: a k-tile pair of 8 rows per load, per-wave
     LDS staging, one piece for M <= 8, two per 16-row tile above) against the fragment-shaped loads they replaced

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libunimedvl_hip.so")
 # the product library (include/unimedvl_hip.h): everything the entry points call.  The kernels that were measured and not adopted
 # live in experimental/ with a build target of their own (python -m experimental.build).
-SOURCES = ["host_error.hip", "elementwise.hip", "gemm.hip", "gemm_w4.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "vision.hip"]
+SOURCES = ["host_error.hip", "elementwise.hip", "pack.hip", "gemm.hip", "gemm_w4.hip", "gemm_fp8mfma.hip", "attention.hip", "attention_prefill.hip", "vision.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 # per-file additions.  attention_prefill: MFMA destinations stay in VGPRs (the compiler's default parks the 64 O accumulators in

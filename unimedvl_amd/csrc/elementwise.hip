@@ -830,6 +830,10 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
     UMV_CHECK((a.qkv || a.qkv_partials) && (v_only || (a.q_out && a.k_slab)) && a.vt_slab && a.tok_seg && a.tok_slot, UMV_ERR_ARG, "qkv_post: null pointer");
     UMV_CHECK(!v_only || (a.qkv && !a.q_norm_w && (a.hd % 8) == 0 && (size_t)8 * a.nkv * a.hd * sizeof(bf16_t) <= 64 * 1024), UMV_ERR_UNSUPPORTED,
               "qkv_post: the V-only split needs bf16 qkv rows, no norm / RoPE and head_dim %% 8 == 0");
+    // v_transpose_kernel stores 8 slots of one V^T row with one 16-byte store: every V^T stride must keep those stores aligned
+    UMV_CHECK(!v_only || ((a.v_d_stride % 8) == 0 && (a.v_head_stride % 8) == 0 && (a.v_seg_stride % 8) == 0), UMV_ERR_UNSUPPORTED,
+              "qkv_post: the V-only split needs V^T strides that are multiples of 8 elements (d %lld, head %lld, segment %lld)",
+              (long long)a.v_d_stride, (long long)a.v_head_stride, (long long)a.v_seg_stride);
     UMV_CHECK(!a.qkv_partials || (a.q_norm_w && a.n_splits >= 1 && a.n_splits <= 64), UMV_ERR_ARG,
               "qkv_post: fp32 partial input needs the norm + RoPE path and 1 <= n_splits <= 64");
     UMV_CHECK(!a.q_norm_w || (a.k_norm_w && a.cos_tab && a.sin_tab && a.tok_pos), UMV_ERR_ARG, "qkv_post: norm without rope tables");

@@ -21,100 +21,6 @@
 #include <string.h>
 #include <stdlib.h>
 
-// ----------------------------------------------------------------------------- packing
-__global__ void pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ p, int N, int K, int NTT,
-                                   int KT, int interleave_I, const bf16_t* __restrict__ w2) {
-    // one thread per 8-element group of the packed image
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)NTT * KT * 64;
-    if (gid >= total) return;
-    int lane = (int)(gid & 63);
-    int64_t tile = gid >> 6;
-    int kt = (int)(tile % KT);
-    int nt = (int)(tile / KT);
-    int r = lane & 15, g = lane >> 4;
-    int k = kt * 32 + g * 8;
-    const bf16_t* src = w;
-    int n;
-    if (interleave_I > 0) {  // swiglu: even tiles gate, odd tiles up
-        int t = nt >> 1;
-        n = t * 16 + r;
-        src = (nt & 1) ? w2 : w;
-        if (n >= interleave_I) n = -1;
-    } else {
-        n = nt * 16 + r;
-        if (n >= N) n = -1;
-    }
-    bf16_t v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (n >= 0 && k + j < K) ? src[(int64_t)n * K + k + j] : (bf16_t)0;
-    u32x4 o;
-    o.x = v[0] | ((uint32_t)v[1] << 16);
-    o.y = v[2] | ((uint32_t)v[3] << 16);
-    o.z = v[4] | ((uint32_t)v[5] << 16);
-    o.w = v[6] | ((uint32_t)v[7] << 16);
-    *reinterpret_cast<u32x4*>(p + gid * 8) = o;
-}
-
-// Re-tile a standard packed image (16-row tiles) into `th`-row tiles for the decode GEMM:
-//   Q[n/th][k/32][g][r < th][k%8]   (th <= 16; th == 16 is the standard image)
-// With th = N / 256 (e.g. 14 rows for N = 3584) the skinny GEMM gets exactly one tile per CU.
-__global__ void repack_rows_kernel(const bf16_t* __restrict__ p16, bf16_t* __restrict__ q, int N, int KT, int th, int64_t total) {
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element group per thread
-    if (gid >= total) return;
-    const int r = (int)(gid % th);
-    const int g = (int)((gid / th) % 4);
-    const int kt = (int)((gid / (4 * th)) % KT);
-    const int64_t nt = gid / ((int64_t)4 * th * KT);
-    const int64_t n = nt * th + r;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (n < N) v = *reinterpret_cast<const u32x4*>(p16 + (((n >> 4) * KT + kt) * 64 + g * 16 + (n & 15)) * 8);
-    *reinterpret_cast<u32x4*>(q + gid * 8) = v;
-}
-
-extern "C" size_t umv_repacked_weight_elems(int N, int K, int th) {
-    size_t nt = ((size_t)N + th - 1) / th, kt = (size_t)(K + 31) / 32;
-    return nt * kt * 4 * th * 8;
-}
-
-extern "C" int umv_repack_weight_rows_bf16(const uint16_t* packed16, uint16_t* out, int N, int K, int th, umv_stream_t stream) {
-    UMV_CHECK(packed16 && out && N > 0 && K > 0 && th >= 1 && th <= 16, UMV_ERR_ARG, "repack_weight_rows: bad args (th=%d)", th);
-    const int KT = (K + 31) / 32;
-    const int64_t total = (int64_t)((N + th - 1) / th) * KT * 4 * th;
-    hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed16, out, N,
-                       KT, th, total);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
-}
-
-extern "C" size_t umv_packed_weight_elems(int N, int K) {
-    size_t ntt = (size_t)(N + 15) / 16, kt = (size_t)(K + 31) / 32;
-    return ntt * kt * 512;
-}
-
-extern "C" int umv_pack_weight_bf16(const uint16_t* w, uint16_t* packed, int N, int K, umv_stream_t stream) {
-    UMV_CHECK(w && packed && N > 0 && K > 0, UMV_ERR_ARG, "pack_weight: bad args");
-    int NTT = (N + 15) / 16, KT = (K + 31) / 32;
-    int64_t total = (int64_t)NTT * KT * 64;
-    int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, N, K, NTT, KT, 0,
-                       (const bf16_t*)nullptr);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
-}
-
-extern "C" int umv_pack_weight_swiglu_bf16(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int I, int K,
-                                           umv_stream_t stream) {
-    UMV_CHECK(gate && up && packed && I > 0 && K > 0, UMV_ERR_ARG, "pack_weight_swiglu: bad args");
-    int NTT = 2 * ((I + 15) / 16), KT = (K + 31) / 32;
-    int64_t total = (int64_t)NTT * KT * 64;
-    int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gate, packed, 2 * I, K, NTT,
-                       KT, I, up);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
-}
-
 // ----------------------------------------------------------------------------- skinny (M <= 64)
 // Weight streaming, HBM-bound.  One workgroup = NT n-tiles x all of K; its 8 waves take
 // contiguous K slices and reduce through LDS.  Each wave keeps U weight fragments per n-tile
@@ -172,7 +78,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
     const int kt_begin = ks0 + wave * kt_per;
     const int kt_end = min(ks1, kt_begin + kt_per);
     // XL works on whole k-tile PAIRS (one 128-byte line of x per row): a slice that starts on an odd k-tile starts one tile early
-    // with that tile's weights masked to zero - an MFMA that adds exact zeros (the x it multiplies is the neighbour wave's, finite)
+    // with that tile's weights masked to zero - an MFMA that adds exact zeros (the x it multiplies is the neighbour wave's, finite).
+    // PRECONDITION of "bit-identical to the plain kernel": x is finite.  Where x holds Inf / NaN in the neighbour's k-tile the masked
+    // product is 0 * Inf = NaN and this wave's partial sum becomes NaN where the plain kernel's would not (the row's final result is
+    // Inf / NaN either way - the neighbour's own product sees the same value; only WHICH of the two non-finite values differs).
     const int kt_lo = XL != 0 ? (kt_begin & ~1) : kt_begin;
     const int nk = max(0, kt_end - kt_lo);
     const int nchunks = (nk + U - 1) / U;
@@ -436,107 +345,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
 //   image: P8[nt][kt8][lane][16 B], lane = g*16 + r; bytes 0..7  <-> W[nt*16 + r][kt8*64 +      g*8 + j]
 //                                                    bytes 8..15 <-> W[nt*16 + r][kt8*64 + 32 + g*8 + j]
 //   scale: f32 [ntt*16] in packed row order (SwiGLU images interleave gate / up 16-row tiles like the bf16 one)
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
 
-__device__ __forceinline__ void cvt_fp8x16(u32x4 q, float scale, bf16x8& lo, bf16x8& hi) {
-    union { bf16x2_hw h[4]; bf16x8 v; } a, b;
-    a.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, false);
-    a.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, true);
-    a.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, false);
-    a.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, true);
-    b.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.z, scale, false);
-    b.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.z, scale, true);
-    b.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.w, scale, false);
-    b.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.w, scale, true);
-    lo = a.v;
-    hi = b.v;
-}
-
-// smallest power of two s with 448 * s >= amax (448 = 0.875 * 2^9 is the largest finite e4m3 value)
-__device__ __forceinline__ float fp8_pow2_scale(float amax) {
-    if (!(amax > 0.f)) return 1.0f;
-    int ea;
-    float ma = frexpf(amax, &ea);   // amax = ma * 2^ea, ma in [0.5, 1)
-    return ldexpf(1.0f, ma <= 0.875f ? ea - 9 : ea - 8);
-}
-
-// One workgroup (256 threads) per packed 16-row tile: row maxima -> scales -> e4m3 image (+ optional W' in bf16).
-__global__ __launch_bounds__(256) void quantize_pack_fp8_kernel(const bf16_t* __restrict__ w, const bf16_t* __restrict__ w2,
-                                                                uint8_t* __restrict__ p8, float* __restrict__ scale,
-                                                                bf16_t* __restrict__ deq, bf16_t* __restrict__ deq2, int rows,
-                                                                int K, int KT8) {
-    __shared__ float smax[16][17];
-    __shared__ float sscale[16];
-    const int nt = blockIdx.x, tid = threadIdx.x;
-    const bool inter = w2 != nullptr;
-    const bf16_t* src = (inter && (nt & 1)) ? w2 : w;
-    bf16_t* dq = (inter && (nt & 1)) ? deq2 : deq;
-    const int row0 = (inter ? (nt >> 1) : nt) * 16;
-    {   // 16 threads per row
-        const int r = tid >> 4, c = tid & 15;
-        float m = 0.f;
-        if (row0 + r < rows)
-            for (int k = c; k < K; k += 16) m = fmaxf(m, fabsf(bf2f(src[(int64_t)(row0 + r) * K + k])));
-        smax[r][c] = m;
-    }
-    __syncthreads();
-    if (tid < 16) {
-        float m = 0.f;
-        for (int c = 0; c < 16; ++c) m = fmaxf(m, smax[tid][c]);
-        const float s = fp8_pow2_scale(m);
-        sscale[tid] = s;
-        scale[nt * 16 + tid] = s;
-    }
-    __syncthreads();
-    // one thread per (kt8, lane) 16-byte group
-    for (int idx = tid; idx < KT8 * 64; idx += 256) {
-        const int lane = idx & 63, kt8 = idx >> 6;
-        const int r = lane & 15, g = lane >> 4;
-        const bool rowok = row0 + r < rows;
-        const float inv = 1.0f / sscale[r];   // exact: a power of two
-        uint32_t o[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k0 = kt8 * 64 + h * 32 + g * 8;
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (rowok && k0 + j < K) ? bf2f(src[(int64_t)(row0 + r) * K + k0 + j]) * inv : 0.f;
-            int lo = 0, hi = 0;
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-            o[2 * h] = (uint32_t)lo;
-            o[2 * h + 1] = (uint32_t)hi;
-            if (dq && rowok) {
-                u32x4 qq = {(uint32_t)lo, (uint32_t)hi, 0u, 0u};
-                bf16x8 d, unused;
-                cvt_fp8x16(qq, sscale[r], d, unused);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (k0 + j < K) dq[(int64_t)(row0 + r) * K + k0 + j] = (bf16_t)d[j];
-            }
-        }
-        u32x4 v = {o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<u32x4*>(p8 + ((int64_t)nt * KT8 * 64 + idx) * 16) = v;
-    }
-}
-
-extern "C" size_t umv_packed_weight_fp8_bytes(int N, int K) {
-    return ((size_t)(N + 15) / 16) * ((size_t)(K + 63) / 64) * 1024;
-}
-
-extern "C" int umv_quantize_pack_weight_fp8(const uint16_t* w, const uint16_t* w_up, uint8_t* packed8, float* scale,
-                                            uint16_t* deq, uint16_t* deq_up, int rows, int K, umv_stream_t stream) {
-    UMV_CHECK(w && packed8 && scale && rows > 0 && K > 0, UMV_ERR_ARG, "quantize_pack_weight_fp8: bad args");
-    UMV_CHECK(!w_up || (rows % 16) == 0, UMV_ERR_ARG, "quantize_pack_weight_fp8: SwiGLU image needs I %% 16 == 0 (I=%d)", rows);
-    UMV_CHECK(!(deq_up && !w_up), UMV_ERR_ARG, "quantize_pack_weight_fp8: deq_up without w_up");
-    const int ntt = (w_up ? 2 : 1) * ((rows + 15) / 16), KT8 = (K + 63) / 64;
-    hipLaunchKernelGGL(quantize_pack_fp8_kernel, dim3(ntt), dim3(256), 0, (hipStream_t)stream, w, w_up, packed8, scale, deq, deq_up,
-                       rows, K, KT8);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
-}
 
 template <int MB, int NT, int U, int XL = 0>
 struct SkBuf8 {
@@ -727,8 +536,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
 }
 
 static int skinny8_xl() {     // UMV_SKINNY8_XL: 0 never, 1 above 8 rows, 2 always (default; A/B only)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UMV_SKINNY8_XL"); v = e ? atoi(e) : 2; }
+    static const int v = umv_env_int("UMV_SKINNY8_XL", 2);
     return v;
 }
 
@@ -791,8 +599,7 @@ extern "C" int umv_gemm_fp8w(const umv_gemm_args* ap, umv_stream_t stream) {
     // (NT, U) from a sweep on MI355X at M = 8 (tools/skinny_bench.py, FP8=1): gate/up 25.5 us with <2,2> (110 VGPRs, two
     // workgroups per CU) vs 33.9 <2,4>, 27.9 <4,1>; down_proj 18.2 us with <1,8> vs 23.7 for NT = 2 (only 112 workgroups)
     if (a.M <= 16) return two ? launch_skinny8<1, 2, 2>(a, KT8, NTT, s) : launch_skinny8<1, 1, 8>(a, KT8, NTT, s);
-    static int nt4 = -1;   // as in umv_gemm_bf16: 4 n-tiles per workgroup on the wide-N GEMMs at M > 16 (UMV_GEMM_SKINNY_NT=2 reverts)
-    if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : 1; }
+    static const int nt4 = umv_env_int("UMV_GEMM_SKINNY_NT", 4) == 2 ? 0 : 1;   // as in umv_gemm_bf16: 4 n-tiles per workgroup on the wide-N GEMMs at M > 16 (UMV_GEMM_SKINNY_NT=2 reverts)
     if (two && nt4) return a.M <= 32 ? launch_skinny8<2, 4, 1>(a, KT8, NTT, s) : launch_skinny8<4, 4, 1>(a, KT8, NTT, s);
     if (a.M <= 32) return two ? launch_skinny8<2, 2, 2>(a, KT8, NTT, s) : launch_skinny8<2, 1, 4>(a, KT8, NTT, s);
     return two ? launch_skinny8<4, 2, 1>(a, KT8, NTT, s) : launch_skinny8<4, 1, 2>(a, KT8, NTT, s);
@@ -853,7 +660,7 @@ __device__ __forceinline__ void mfma32_asm(f32x16& c, const bf16x8& a, const bf1
 // SCHED = 1: the same pipeline with the MFMAs of tile t and the ds_reads of tile t+1 interleaved by hand (see below).
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
 __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn,
-                                                                  int ksplit, int ms) {
+                                                                  int ksplit, int ms, int lean) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16 * KTS, XTILES = BM / 16 * KTS;      // 1 KiB fragment tiles per k-step
@@ -1337,6 +1144,12 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     constexpr bool LDS_EPI = BN * BM * 2 <= STAGE_BYTES;
     if (LDS_EPI && !(e.flags & UMV_EPI_OUT_F32) && lds_epilogue_enabled) {
         UMV_BARRIER();      // every wave has read its last fragments: the staging buffers are free
+        // lean >= 0: the branch-free form of gemm_epilogue.h for this call's flag combination (epi_lean_kind); bit-identical
+        if constexpr (!M32) {
+            if (lean >= 0 && !ksplit &&
+                epi_wave_tile_lean_any<TN, TM>(lean, a, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, nt_base, bias_lds + wn * TN * 16))
+                return;
+        }
         epi_wave_tile_lds<TN, TM, M32>(e, acc, smem + wave * (TN * TM * 512), lane, m0 + wm * TM * 16, a.M, a.row_idx, nt_base, NTT,
                                        bias_lds + wn * TN * 16);
         return;
@@ -1390,9 +1203,15 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
 }
 
 static int raster_gn() {   // n-blocks per strip of the tile order; UMV_GEMM_RASTER overrides (tuning only)
-    static int gn = -1;
-    if (gn < 0) { const char* e = getenv("UMV_GEMM_RASTER"); gn = e ? atoi(e) : 4; if (gn < 1) gn = 1; }
+    static const int gn = umv_env_int("UMV_GEMM_RASTER", 4) < 1 ? 1 : umv_env_int("UMV_GEMM_RASTER", 4);
     return gn;
+}
+
+// the epilogue form of a tiled call: >= 0 = gemm_epilogue.h's lean form for this flag combination, -1 = the general one
+// (UMV_GEMM_LEAN_EPI=0: always the general one - A/B, tuning only; results are bit-identical)
+int umv_gemm_lean_epilogue(const umv_gemm_args& a) {
+    static const int on = umv_env_int("UMV_GEMM_LEAN_EPI", 1);
+    return on ? epi_lean_kind(a) : -1;
 }
 
 template <int WN, int WM, int TN, int TM, int KTS, int NBUF, int SCHED = 0>
@@ -1413,8 +1232,7 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     const int splits = a.k_splits > 1 ? a.k_splits : 1;
     const int ksplit = splits > 1 ? ((KT + splits - 1) / splits + KTS - 1) / KTS * KTS : 0;    // whole k-steps per split
     // m-blocks per super-block: ~64 MB of x rows (UMV_GEMM_MSB overrides, tuning only; 0 = one super-block)
-    static int msb_env = -1;
-    if (msb_env < 0) { const char* e = getenv("UMV_GEMM_MSB"); msb_env = e ? atoi(e) : -2; }
+    static const int msb_env = umv_env_int("UMV_GEMM_MSB", -2);
     int ms = (int)(((int64_t)64 << 20) / ((int64_t)BM * a.K * 2));
     ms = ms < 8 ? 8 : ms;
     if ((int64_t)mblocks * BM < 16384) ms = mblocks;   // measured (us, on / off): M = 32 832 gate/up 7040 / 7480, down 3880 / 4070, qkv 1013 / 1056;
@@ -1423,7 +1241,7 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
     if (ms > mblocks || ms * 3 / 2 >= mblocks) ms = mblocks;        // a short second super-block is not worth a second pass over W
     else ms = (mblocks + (mblocks + ms - 1) / ms - 1) / ((mblocks + ms - 1) / ms);   // equal super-blocks: no stub at the end
     hipLaunchKernelGGL((gemm_tiled_kernel<WN, WM, TN, TM, KTS, NBUF, SCHED>), dim3(mblocks * nblocks, splits), dim3(WN * WM * 64), lds, s, a,
-                       KT, NTT, mblocks, nblocks, raster_gn(), ksplit, ms);
+                       KT, NTT, mblocks, nblocks, raster_gn(), ksplit, ms, umv_gemm_lean_epilogue(a));
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -1435,8 +1253,7 @@ static int launch_tiled(const umv_gemm_args& a, int KT, int NTT, hipStream_t s) 
 // registers: 42.4 -> 45.4 us), the ONE-piece form (rows 0..7 only, 124 registers) wins: gate/up 42.5 -> 41.4 (6.57 TB/s), down
 // 26.0 -> 24.7, qkv 11.4 -> 9.2, headline step 3.161 -> 3.111 ms.
 static int skinny_xl() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UMV_SKINNY_XL"); v = e ? atoi(e) : 2; }
+    static const int v = umv_env_int("UMV_SKINNY_XL", 2);
     return v;
 }
 
@@ -1482,9 +1299,18 @@ static int launch_skinny(const umv_gemm_args& a, int KT, int NTT, hipStream_t s)
 // 128 x 128 with two workgroups per CU (M ~ 1024: 560-680), then 128(n) x 64(m).
 // UMV_GEMM_TILE=<256|266|258|268|384|288|129|130|270|64> overrides (tuning only).
 // Exported so that tests can assert which kernel a shape is sent to (returns 0 for M <= 64: weight-streaming kernels).
+// compute units of the current device (256 on MI355X; 256 as well when no device answers - the policy is also queried on hosts without one)
+static int umv_cu_count() {
+    static const int n = [] {
+        int d = 0, v = 0;
+        if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
 extern "C" int umv_gemm_tile_config(int M, int N, int K) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("UMV_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    static const int force = umv_env_int("UMV_GEMM_TILE", 0);
     if (force) return force;
     if (M <= 64) return 0;
     const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256);
@@ -1498,7 +1324,7 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
         // it is 192 tiles of 3/4 the work: rounds x tile area decides (out 46.7 -> 37.3 us, fc2 103.8 -> 89.9, fc1 (N = 4304: 544
         // tiles = 2.1 rounds against 768 = 3 rounds of 3/4) 120.3 -> 111.7; the fused q/k/v GEMM, N = 3456, stays on
         // 256 x 256: 76 vs 95 us)
-        const long cus = 256, t384 = (long)((M + 127) / 128) * ((N + 383) / 384);
+        const long cus = umv_cu_count(), t384 = (long)((M + 127) / 128) * ((N + 383) / 384);
         const long c266 = (wg256 + cus - 1) / cus * 65536, c384 = (t384 + cus - 1) / cus * 49152;
         // 288 x 128 (round 3): N = 1152 / 4608 = 4 / 16 x 288 columns give exactly 256 tiles at 8192 / 2048 rows where 384 x 128 fills
         // 192 of the 256 CUs.  Its 18 MFMAs per k-step carry the same per-step overhead as the bigger tiles' 24 - 32 (about 0.8 of
@@ -1513,8 +1339,7 @@ extern "C" int umv_gemm_tile_config(int M, int N, int K) {
         // (profiles/r04_m272_tiles.txt); the same rule sends the 65..128-row decode gate/up GEMM to 148 tiles of 256 x 128 instead of 99 of
         // 384 x 128: 128 samples 7.80 -> 7.47 ms per step, 96: 7.07 -> 6.76, 72: 6.50 -> 6.17 (profiles/r04_fewrow_tile.txt)
         const long c268 = (wg258 + cus - 1) / cus * 32768 * 115 / 100;
-        static int fewrow = -1;      // UMV_GEMM_FEWROW=0: without this rule (A/B, tuning only)
-        if (fewrow < 0) { const char* e = getenv("UMV_GEMM_FEWROW"); fewrow = e ? atoi(e) : 1; }
+        static const int fewrow = umv_env_int("UMV_GEMM_FEWROW", 1);      // UMV_GEMM_FEWROW=0: without this rule (A/B, tuning only)
         if (fewrow && M <= 512 && c268 < c384 && c268 < c266) return 268;
         if (c384 * 10 < c266 * 9) return 384;
     }
@@ -1552,13 +1377,9 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     UMV_CHECK(TH == 16 || (a.M <= 64 && !(a.epilogue & UMV_EPI_SWIGLU)), UMV_ERR_UNSUPPORTED,
               "gemm: %d-row packed tiles are a decode-only layout (M <= 64, no SwiGLU)", TH);
     const int NTT = (a.N + TH - 1) / TH;
-    static int skinny_max = -1;   // tuning only: UMV_GEMM_SKINNY_MAX=<M> (rows up to which the weight-streaming kernel is used)
-    if (skinny_max < 0) { const char* e = getenv("UMV_GEMM_SKINNY_MAX"); skinny_max = e ? atoi(e) : 64; }
-    static int sk_tiled_min = -1;   // tuning only: UMV_SPLITK_TILED_MIN=<rows from which split-K runs on the tiled kernel>
-    if (sk_tiled_min < 0) { const char* e = getenv("UMV_SPLITK_TILED_MIN"); sk_tiled_min = e ? atoi(e) : 65; }
-    static int sk_xl = -1;          // UMV_SPLITK_TILED_XL=0: the half-line staging of the 65..128-row split-K tile (A/B, tuning only; bit-identical;
-                                    // full-line staging: 128-sample decode step 7.69 -> 7.62 ms, 96 samples 7.03 -> 6.87 ms)
-    if (sk_xl < 0) { const char* e = getenv("UMV_SPLITK_TILED_XL"); sk_xl = e ? atoi(e) : 1; }
+    static const int skinny_max = umv_env_int("UMV_GEMM_SKINNY_MAX", 64);   // tuning only: UMV_GEMM_SKINNY_MAX=<M> (rows up to which the weight-streaming kernel is used)
+    static const int sk_tiled_min = umv_env_int("UMV_SPLITK_TILED_MIN", 65);   // tuning only: UMV_SPLITK_TILED_MIN=<rows from which split-K runs on the tiled kernel>
+    static const int sk_xl = umv_env_int("UMV_SPLITK_TILED_XL", 1);          // UMV_SPLITK_TILED_XL=0: the half-line staging of the 65..128-row split-K tile (A/B, tuning only; bit-identical;
     if (a.k_splits > 1 && (a.M > 64 || a.M >= sk_tiled_min) && TH == 16) {  // 65..128 rows: the 128 x 128 tile (two workgroups per CU) over k_splits K ranges, fp32 partials
         if (sk_xl) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
         return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);
@@ -1570,8 +1391,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // 3.176 ms per step: no)
         if (a.M <= 16) return launch_skinny<1, 4, 2, true, 0>(a, KT, NTT, s);
         if (a.M <= 32) {
-            static int v32 = -1;    // tuning only: UMV_SKINNY_M32=<0|1|2>
-            if (v32 < 0) { const char* e = getenv("UMV_SKINNY_M32"); v32 = e ? atoi(e) : 0; }
+            static const int v32 = umv_env_int("UMV_SKINNY_M32", 0);    // tuning only: UMV_SKINNY_M32=<0|1|2>
             if (v32 == 1) return launch_skinny<2, 4, 1, true, 0>(a, KT, NTT, s);
             if (v32 == 2) return launch_skinny<2, 2, 2, true, 0>(a, KT, NTT, s);
             return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
@@ -1589,14 +1409,12 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         }
         // M > 16: every workgroup re-reads all of x from L2, so wide-N GEMMs take 4 n-tiles per workgroup (x : weight bytes
         // = M : 64); UMV_GEMM_SKINNY_NT=2 restores the 2-tile kernels (tuning only)
-        static int nt4 = -1;
-        if (nt4 < 0) { const char* e = getenv("UMV_GEMM_SKINNY_NT"); nt4 = (e && atoi(e) == 2) ? 0 : (e && atoi(e) == 8) ? 8 : 1; }
+        static const int nt4_env = umv_env_int("UMV_GEMM_SKINNY_NT", 4), nt4 = nt4_env == 2 ? 0 : nt4_env == 8 ? 8 : 1;
         // (the 128 x 64 full-line tile at 17..32 rows: 32 samples 3.99 -> 4.09 ms per step, 24: 3.80 -> 3.92, 17: 3.62 -> 3.74 - the
         // weight-streaming kernel keeps these rows; profiles/r04_midbatch_xline.txt)
         if (two && nt4 == 8 && TH == 16 && a.M <= 32) return launch_skinny<2, 8, 1, true, 0>(a, KT, NTT, s);
         if (two && nt4 && TH == 16 && a.M <= 32) {
-            static int v32 = -1;
-            if (v32 < 0) { const char* e = getenv("UMV_SKINNY_M32"); v32 = e ? atoi(e) : 0; }
+            static const int v32 = umv_env_int("UMV_SKINNY_M32", 0);
             if (v32 == 1) return launch_skinny<2, 4, 1, true, 0>(a, KT, NTT, s);
             if (v32 == 2) return launch_skinny<2, 2, 2, true, 0>(a, KT, NTT, s);
             return launch_skinny<2, 4, 2, true, 0>(a, KT, NTT, s);
@@ -1604,8 +1422,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // 33..64 rows on the wide-N GEMMs: the LDS-staged tile 128(n) x 64(m) x 64 reads x once per 128 columns instead of once
         // per 64 and streams gate/up in 73 us against 84 for the 4-tile skinny kernel (tools/stream_tile_bench.py 64); at
         // <= 32 rows the skinny kernel wins (60 vs 64-66 us).  Not with the argmax epilogue (skinny kernels only).
-        static int m64 = -1;
-        if (m64 < 0) { const char* e = getenv("UMV_GEMM_M64_TILED"); m64 = e ? atoi(e) : 2; }
+        static const int m64 = umv_env_int("UMV_GEMM_M64_TILED", 2);
         // UMV_GEMM_M64_TILED=2 (default): the same tile with k-steps of 32 and x staged in full 128-byte lines (SCHED = 3, 48 KiB, 3 WG/CU):
         // bit-identical, 64-sample decode step 5.65 -> 5.42 ms, 40 samples 4.82 -> 4.60 ms; 1 = the 64-wide k-step tile, 0 = skinny
         if (two && TH == 16 && m64 == 2 && a.M > 32 && !a.argmax_partial && !a.norm_w && a.K >= 1024) return launch_tiled<4, 1, 2, 4, 1, 4, 3>(a, KT, NTT, s);
@@ -1619,9 +1436,11 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // Bit-identical results; end to end on MI355X (tools/stage_profile.py, same box): text-to-image 1530 -> 1443 ms per batch of 4,
         // prefill of 8 images 131.7 -> 130.7 ms, ViT tower 12.70 -> 12.50 ms.  (A 20-launch microbenchmark from a cold chip shows the
         // opposite sign, -2..-8 %: the variant pays a longer prologue and wins only at the clocks a sustained load runs at.)
-        static int xline = -1;
-        if (xline < 0) { const char* e = getenv("UMV_GEMM_XLINE"); xline = e ? atoi(e) : 1; }      // (2: also the 288-column tile, under evaluation)
-        if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : (cfg == 288 && xline > 1) ? 388 : cfg;
+        static const int xline = umv_env_int("UMV_GEMM_XLINE", 1);      // (2: also the 288-column tile, under evaluation)
+        if (xline) cfg = cfg == 266 ? 366 : cfg == 268 ? 368 : cfg == 384 ? 484 : cfg == 270 ? 370 : cfg;
+#ifdef UMV_GEMM_ABLATIONS
+        if (xline > 1 && cfg == 288) cfg = 388;      // the 288-column tile with full-line staging: measured, not adopted (ablation builds only)
+#endif
     }
     {   // round 5: the 4-wave tiles with the accumulators in AGPRs (gemm_w4.hip) take over the 8-wave tiles of the same shape on the
         // LLM's GEMMs (K = 3584 / 18944): bit-identical results (same MFMAs, operands and k order), sustained loops on MI355X
@@ -1631,8 +1450,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         // 256-register epilogue on four waves cost more than the 8-wave tile's at K = 1152 (SigLIP q/k/v 67.8 -> 80.6 us, fc1
         // 85.8 -> 103.4 us, tower 11.6 -> 12.3 ms with the 4-wave tiles everywhere), so the rule is K >= 2048.
         // UMV_GEMM_W4=0: the 8-wave tiles everywhere, 2: the 4-wave tiles at every K (A/B, tuning only)
-        static int w4 = -1;
-        if (w4 < 0) { const char* e = getenv("UMV_GEMM_W4"); w4 = e ? atoi(e) : 1; }
+        static const int w4 = umv_env_int("UMV_GEMM_W4", 1);
         const int c4 = cfg == 366 ? 466 : cfg == 368 ? 468 : cfg == 484 ? 4384 : 0;
         if (w4 && c4 && (w4 == 2 || a.K >= 2048) && umv_gemm_w4_can_take(a, KT, NTT)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
     }
@@ -1666,7 +1484,9 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 368) return launch_tiled<4, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
     if (cfg == 484) return launch_tiled<4, 2, 6, 4, 1, 4, 3>(a, KT, NTT, s);
     if (cfg == 370) return launch_tiled<2, 2, 4, 4, 1, 4, 3>(a, KT, NTT, s);
+#ifdef UMV_GEMM_ABLATIONS
     if (cfg == 388) return launch_tiled<2, 4, 9, 2, 1, 4, 3>(a, KT, NTT, s);   // 288(n) x 128(m) with full-line x staging (18 W tiles on 8 waves: 3 slots each, 6 of them idle)
+#endif
     if (cfg == 268) return launch_tiled<4, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 256(n)x128(m)x32, 8 waves as 4x2, interleaved
     if (cfg == 384) return launch_tiled<4, 2, 6, 4, 1, 4, 1>(a, KT, NTT, s);   // 384(n)x128(m)x32, 8 waves of 96 x 64: N = 1152 = 3 x 384 without padding
     if (cfg == 270) return launch_tiled<2, 2, 4, 4, 1, 4, 1>(a, KT, NTT, s);   // 128x128x32, 4 waves, 4 buffers (64 KiB, 2 WG/CU), interleaved

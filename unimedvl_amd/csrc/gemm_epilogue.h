@@ -347,3 +347,167 @@ __device__ __forceinline__ void epi_wave_tile_lds(const EpiCtx& e, f32x4 (&acc)[
     }
 }
 
+
+// ----------------------------------------------------------------------------- lean wave-tile epilogue (round 5)
+// epi_wave_tile_lds above decides everything at run time, per quad and per row: which flags are set, whether a row / a chunk is
+// inside the matrix, whether a pointer is 16-byte aligned.  Unrolled over a 128 x 128 wave tile that is ~20 000 instructions with
+// ~1200 branches, and the tile-level trace of the 4-wave kernel (profiles/r05_w4_tile_trace.txt) shows what it costs: ~35 000
+// cycles per 256 x 256 tile - three quarters of the whole k loop at K = 1152, a fifth at K = 3584 - where the store path takes the
+// same 128 KiB per CU from every CU at once in ~12 000 (tools/store_bench.hip).
+// The lean form serves the flag combinations the model uses (KIND, compile time) on outputs whose rows are 16-byte aligned and
+// addressable with 32-bit offsets (epi_lean_kind); everything else keeps the general function.  Same two phases through the wave's
+// own LDS region, same arithmetic and rounding points (bit-identical results), but
+//   * no per-element decisions: rows beyond M and chunks beyond N are dropped by the buffer range check of
+//     buffer_store_dwordx4 / answered with zeros by buffer_load_dwordx4 (dense: num_records = M rows; row-indexed: an
+//     out-of-range offset for the lanes concerned), so the loops carry no branches;
+//   * LDS addresses are one lane constant XOR a compile-time constant (power-of-two chunk counts) plus an immediate offset;
+//   * pack2bf(rbf(x)) is pack2bf(x): a value that is only stored is rounded once;
+//   * the residual rows of the whole tile are requested before the first one is needed.
+// KIND bits: 1 bias, 2 GELU(tanh) [with bias], 4 residual, 8 SwiGLU.
+__host__ __device__ inline int epi_lean_kind(const umv_gemm_args& a) {
+    const int f = a.epilogue;
+    if (!(f == 0 || f == UMV_EPI_BIAS || f == (UMV_EPI_BIAS | UMV_EPI_GELU_TANH) || f == UMV_EPI_RESIDUAL || f == (UMV_EPI_BIAS | UMV_EPI_RESIDUAL) ||
+          f == UMV_EPI_SWIGLU))
+        return -1;
+    const int kind = ((f & UMV_EPI_BIAS) ? 1 : 0) | ((f & UMV_EPI_GELU_TANH) ? 2 : 0) | ((f & UMV_EPI_RESIDUAL) ? 4 : 0) | ((f & UMV_EPI_SWIGLU) ? 8 : 0);
+    const int n_out = (f & UMV_EPI_SWIGLU) ? a.N / 2 : a.N;
+    if ((f & UMV_EPI_SWIGLU) && (a.N & 31)) return -1;
+    if ((n_out & 7) || (a.ldo & 7) || (reinterpret_cast<uintptr_t>(a.out) & 15) || a.ldo < n_out) return -1;
+    const int64_t rows = a.row_idx ? a.x_rows : (int64_t)a.M;
+    const int64_t lim = (int64_t)1 << 31;
+    if (rows <= 0 || rows * a.ldo * 2 >= lim) return -1;
+    if ((f & UMV_EPI_RESIDUAL) && ((a.ldr & 7) || (reinterpret_cast<uintptr_t>(a.residual) & 15) || a.ldr < n_out || rows * a.ldr * 2 >= lim)) return -1;
+    return kind;
+}
+
+template <int CH>
+__device__ __forceinline__ int epi_wrap(int p) { return p >= CH ? p - CH : p; }
+
+template <int TN, int TM, int KIND>
+__device__ __forceinline__ void epi_wave_tile_lean(const umv_gemm_args& a, f32x4 (&acc)[TN][TM], char* wreg, int lane, int m_wave0, int nt_base,
+                                                   const bf16_t* bias_tile /* LDS: bias[nt_base * 16 ..], zero past N */) {
+    constexpr bool BIAS = (KIND & 1) != 0, GELU = (KIND & 2) != 0, RES = (KIND & 4) != 0, SWI = (KIND & 8) != 0;
+    constexpr int CH = SWI ? TN : 2 * TN;                  // 16-byte chunks per row of the wave's output tile
+    constexpr int ROWB = CH * 16, RPI = 64 / CH, NI = (TM * 16 + RPI - 1) / RPI;
+    constexpr bool P2 = (CH & (CH - 1)) == 0;
+    constexpr int NQ = SWI ? TN / 2 : TN;                  // column groups of phase 1 (tiles, or gate / up tile pairs)
+    static_assert(CH <= 16 || !P2, "row & (CH - 1) == lane & (CH - 1) needs CH <= 16");
+    const int r = lane & 15, g = lane >> 4, gh = g >> 1;
+    const int n_out = SWI ? a.N / 2 : a.N;
+    const int col_base = SWI ? (nt_base >> 1) * 16 : nt_base * 16;
+    const uint32_t ldo2 = (uint32_t)a.ldo * 2u, ldr2 = (uint32_t)a.ldr * 2u;
+    // ---- where this lane's rows of phase 2 go (row-indexed outputs: ask for the indices now)
+    const int row_l = lane / CH, chunk = lane % CH;
+    const bool lane_ok = row_l < RPI && col_base + chunk * 8 < n_out;
+    const uint32_t colb = (uint32_t)(col_base + chunk * 8) * 2u;
+    int32_t ridx[NI];
+    if (a.row_idx) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = m_wave0 + i * RPI + row_l;
+            ridx[i] = a.row_idx[m < a.M ? m : a.M - 1];
+        }
+    }
+    // ---- phase 1: accumulator layout -> bf16 -> LDS, row (j * 16 + r), chunk 2q + gh, 8-byte half g & 1
+    const int L = P2 ? r * ROWB + ((gh ^ (r & (CH - 1))) << 4) + (g & 1) * 8 : r * ROWB + (g & 1) * 8;
+    const int c0m = (gh + r) % CH;
+    static_for<0, NQ>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIAS) {
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(bias_tile + q * 16 + g * 4);
+            b4[0] = __uint_as_float(pk.x << 16); b4[1] = __uint_as_float(pk.x & 0xFFFF0000u);
+            b4[2] = __uint_as_float(pk.y << 16); b4[3] = __uint_as_float(pk.y & 0xFFFF0000u);
+        }
+        static_for<0, TM>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            float v[4];
+            if constexpr (SWI) {
+                const float gg[4] = {acc[2 * q][j].x, acc[2 * q][j].y, acc[2 * q][j].z, acc[2 * q][j].w};
+                const float uu[4] = {acc[2 * q + 1][j].x, acc[2 * q + 1][j].y, acc[2 * q + 1][j].z, acc[2 * q + 1][j].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = rbf(silu_f(rbf(gg[k]))) * rbf(uu[k]);     // (the product is rounded by the pack below)
+            } else {
+                v[0] = acc[q][j].x; v[1] = acc[q][j].y; v[2] = acc[q][j].z; v[3] = acc[q][j].w;
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += b4[k];
+                }
+                if constexpr (GELU) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = gelu_tanh_f(rbf(v[k]));
+                }
+            }
+            u32x2 pk;
+            pk.x = pack2bf(v[0], v[1]);
+            pk.y = pack2bf(v[2], v[3]);
+            int off;
+            if constexpr (P2) off = (L ^ (q << 5)) + j * 16 * ROWB;
+            else off = L + j * 16 * ROWB + (epi_wrap<CH>(c0m + (2 * q + 16 * j) % CH) << 4);
+            *reinterpret_cast<u32x2*>(wreg + off) = pk;
+        });
+    });
+    // ---- phase 2: whole rows; an instruction covers RPI rows of ROWB bytes
+    const int64_t nrows = a.row_idx ? 0 : (int64_t)a.M;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.row_idx ? 0x7FFFFFFF : (int)(nrows * ldo2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(RES ? a.residual : (const bf16_t*)a.out), 0,
+                                                                            a.row_idx ? 0x7FFFFFFF : (int)(nrows * (RES ? ldr2 : ldo2)), 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+    uint32_t vo[NI], vr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        bool ok = lane_ok;
+        if (i * RPI + RPI > TM * 16) ok = ok && (i * RPI + row_l < TM * 16);       // (chunk counts that do not divide 64: the last instruction overshoots)
+        if (a.row_idx) {
+            ok = ok && (m_wave0 + i * RPI + row_l < a.M);
+            vo[i] = ok ? (uint32_t)ridx[i] * ldo2 + colb : OOB;
+            if constexpr (RES) vr[i] = ok ? (uint32_t)ridx[i] * ldr2 + colb : OOB;
+        } else {
+            vo[i] = ok ? (uint32_t)(m_wave0 + i * RPI + row_l) * ldo2 + colb : OOB;
+            if constexpr (RES) vr[i] = ok ? (uint32_t)(m_wave0 + i * RPI + row_l) * ldr2 + colb : OOB;
+        }
+    }
+    u32x4 rv[RES ? NI : 1];
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, vr[i], 0, 0);
+    }
+    const int rl = row_l & (CH - 1);
+    const int R = P2 ? row_l * ROWB + ((chunk ^ rl) << 4) : row_l * ROWB;
+    const int c1 = (chunk + row_l) % CH;
+    static_for<0, NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        int off;
+        if constexpr (P2) off = (R ^ (((i * RPI) & (CH - 1)) << 4)) + i * RPI * ROWB;
+        else off = R + i * RPI * ROWB + (epi_wrap<CH>(c1 + (i * RPI) % CH) << 4);
+        if constexpr (!P2) off = row_l < RPI ? off : 0;                          // idle lanes read a valid address
+        u32x4 v = *reinterpret_cast<const u32x4*>(wreg + off);
+        if constexpr (RES) {
+            const uint32_t rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+            uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                vw[k] = pack2bf(__uint_as_float(vw[k] << 16) + __uint_as_float(rw[k] << 16),
+                                __uint_as_float(vw[k] & 0xFFFF0000u) + __uint_as_float(rw[k] & 0xFFFF0000u));
+            v.x = vw[0]; v.y = vw[1]; v.z = vw[2]; v.w = vw[3];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, vo[i], 0, 0);
+    });
+}
+
+// dispatch on the run-time kind (wave-uniform); returns false when the general function must be used
+template <int TN, int TM>
+__device__ __forceinline__ bool epi_wave_tile_lean_any(int kind, const umv_gemm_args& a, f32x4 (&acc)[TN][TM], char* wreg, int lane, int m_wave0,
+                                                       int nt_base, const bf16_t* bias_tile) {
+    switch (kind) {
+    case 0: epi_wave_tile_lean<TN, TM, 0>(a, acc, wreg, lane, m_wave0, nt_base, bias_tile); return true;
+    case 1: epi_wave_tile_lean<TN, TM, 1>(a, acc, wreg, lane, m_wave0, nt_base, bias_tile); return true;
+    case 3: epi_wave_tile_lean<TN, TM, 3>(a, acc, wreg, lane, m_wave0, nt_base, bias_tile); return true;
+    case 4: epi_wave_tile_lean<TN, TM, 4>(a, acc, wreg, lane, m_wave0, nt_base, bias_tile); return true;
+    case 5: epi_wave_tile_lean<TN, TM, 5>(a, acc, wreg, lane, m_wave0, nt_base, bias_tile); return true;
+    case 8:
+        if constexpr (TN % 2 == 0) { epi_wave_tile_lean<TN, TM, 8>(a, acc, wreg, lane, m_wave0, nt_base, bias_tile); return true; }
+        return false;
+    default: return false;
+    }
+}

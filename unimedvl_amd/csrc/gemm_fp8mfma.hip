@@ -22,39 +22,6 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((address_space(3))) void* lds8_ptr_t;
 __device__ __attribute__((aligned(16))) const uint32_t g_zero_page8[4] = {0, 0, 0, 0};
 
-// ----------------------------------------------------------------------------- weight image for the MFMA
-// from the decode image P8[nt][k/64][lane = g*16 + r][16 B: (k%64)/32 * 8 + k%8]; one thread per 8-byte piece
-__global__ void repack_fp8_mfma_kernel(const uint8_t* __restrict__ p8, uint8_t* __restrict__ out, int KT8, int KT128, int64_t total) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // ((nt*KT128 + kt)*2 + h)*64 + lane)*2 + half
-    if (gid >= total) return;
-    const int half = (int)(gid & 1);
-    const int lane = (int)((gid >> 1) & 63);
-    const int h = (int)((gid >> 7) & 1);
-    const int64_t tile = gid >> 8;
-    const int kt = (int)(tile % KT128);
-    const int64_t nt = tile / KT128;
-    const int r = lane & 15, g = lane >> 4;
-    const int k0 = kt * 128 + g * 32 + h * 16 + half * 8;
-    const int kt8 = k0 >> 6, rem = k0 & 63;
-    u32x2 v = {0u, 0u};
-    if (kt8 < KT8) v = *reinterpret_cast<const u32x2*>(p8 + ((nt * KT8 + kt8) * 64 + ((rem & 31) >> 3) * 16 + r) * 16 + (rem >> 5) * 8);
-    *reinterpret_cast<u32x2*>(out + gid * 8) = v;
-}
-
-extern "C" size_t umv_packed_weight_fp8_mfma_bytes(int N, int K) {
-    return ((size_t)(N + 15) / 16) * ((size_t)(K + 127) / 128) * 2048;
-}
-
-extern "C" int umv_repack_weight_fp8_mfma(const uint8_t* packed8, uint8_t* out, int N, int K, umv_stream_t stream) {
-    UMV_CHECK(packed8 && out && N > 0 && K > 0, UMV_ERR_ARG, "repack_weight_fp8_mfma: bad args");
-    const int KT8 = (K + 63) / 64, KT128 = (K + 127) / 128;
-    const int64_t total = (int64_t)((N + 15) / 16) * KT128 * 2 * 64 * 2;
-    hipLaunchKernelGGL(repack_fp8_mfma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed8, out,
-                       KT8, KT128, total);
-    UMV_LAUNCH_CHECK();
-    return UMV_OK;
-}
-
 // ----------------------------------------------------------------------------- activations: per-row e4m3
 __device__ __forceinline__ float act_pow2_scale(float amax) {   // smallest 2^e with 448 * 2^e >= amax (1 for a zero row)
     if (!(amax > 0.f)) return 1.0f;

@@ -3,6 +3,14 @@
 #pragma once
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
+#include <stdlib.h>
+
+// A/B and tuning knobs are read from the environment ONCE per process: `static const int v = umv_env_int("NAME", default);` at the
+// point of use (the initialisation of a function-local static is thread-safe)
+static inline int umv_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 // read r of NRD goes right after MFMA number (r * SPAN) / NRD, SPAN = 3/4 of the step's MFMAs: evenly spread over the first three
 // quarters, first one after the first MFMA, so that the last quarter's MFMAs cover the latency of the last reads before the
@@ -52,5 +60,22 @@ static inline int umv_tile_superblock(int mblocks, int BM, int K) {
 
 // gemm_w4.hip: 4-wave tiles with the accumulators in AGPRs (cfg 466 / 468 / 4384); bf16 output, no split-K, operands within
 // 2 GiB of their base pointers (umv_gemm_w4_can_take)
+int umv_gemm_lean_epilogue(const umv_gemm_args& a);      // gemm.hip: >= 0 = the lean epilogue kind of this call, -1 = general
 bool umv_gemm_w4_can_take(const umv_gemm_args& a, int KT, int NTT);
 int umv_gemm_w4_launch(const umv_gemm_args& a, int KT, int NTT, int cfg, int gn, hipStream_t s);
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+// 16 e4m3 values x one power-of-two scale -> 16 bf16 (exact: an e4m3 value times 2^e is a bf16 value)
+__device__ __forceinline__ void cvt_fp8x16(u32x4 q, float scale, bf16x8& lo, bf16x8& hi) {
+    union { bf16x2_hw h[4]; bf16x8 v; } a, b;
+    a.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, false);
+    a.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, true);
+    a.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, false);
+    a.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, true);
+    b.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.z, scale, false);
+    b.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.z, scale, true);
+    b.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.w, scale, false);
+    b.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.w, scale, true);
+    lo = a.v;
+    hi = b.v;
+}

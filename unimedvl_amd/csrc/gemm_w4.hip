@@ -65,7 +65,7 @@ __device__ __forceinline__ float w4_acc_read() {
 // buffer_load_dwordx4 ... offen lds with ONE offset VGPR per piece for the whole kernel; K advances in the scalar offset
 // (clamped at the last k-tile / pair: the trailing bodies re-stage data nobody reads).
 template <int WN, int WM, int TN, int TM, int ABL = 0, bool RAGK = false>
-__global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn, int ms) {
+__global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, int KT, int NTT, int mblocks, int nblocks, int gn, int ms, int lean) {
     constexpr int NW = WN * WM;
     constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
     constexpr int WTILES = BN / 16;
@@ -267,8 +267,10 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
                 acc[t][jj] = (f32x4){w4_acc_read<idx>(), w4_acc_read<idx + 1>(), w4_acc_read<idx + 2>(), w4_acc_read<idx + 3>()};
             });
         });
-        epi_wave_tile_lds<TN, JC, false>(e, acc, wreg, lane, m0 + wm * TM * 16 + h * JC * 16, a.M, a.row_idx, nt_base, NTT,
-                                        bias_lds + wn * TN * 16);
+        // lean >= 0: the branch-free form for this call's flag combination (gemm_epilogue.h::epi_lean_kind), else the general one
+        if (!(lean >= 0 && epi_wave_tile_lean_any<TN, JC>(lean, a, acc, wreg, lane, m0 + wm * TM * 16 + h * JC * 16, nt_base, bias_lds + wn * TN * 16)))
+            epi_wave_tile_lds<TN, JC, false>(e, acc, wreg, lane, m0 + wm * TM * 16 + h * JC * 16, a.M, a.row_idx, nt_base, NTT,
+                                            bias_lds + wn * TN * 16);
         if constexpr (ABL == 2 && h == 0) w4_stamp(tw3);
     });
     if constexpr (ABL == 2) {
@@ -300,7 +302,8 @@ static int launch_w4(const umv_gemm_args& a, int KT, int NTT, int gn, hipStream_
         static bool attr_set[UMV_MAX_DEVICES] = {};
         if (umv_first_on_device(attr_set))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<WN, WM, TN, TM, ABL, ragk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm_w4_kernel<WN, WM, TN, TM, ABL, ragk>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks, nblocks, gn, ms);
+        hipLaunchKernelGGL((gemm_w4_kernel<WN, WM, TN, TM, ABL, ragk>), dim3(mblocks * nblocks), dim3(WN * WM * 64), lds, s, a, KT, NTT, mblocks, nblocks, gn, ms,
+                           umv_gemm_lean_epilogue(a));
     };
     if (a.K % 32) go(std::true_type{});
     else go(std::false_type{});

@@ -9,7 +9,8 @@ the RESULT of all that: `ema_packed_<dtype>.safetensors` beside the checkpoint h
 reads each tensor straight onto the device and builds nothing; an fp32 source checkpoint is no longer read at all.
 
 The file is only trusted for the checkpoint, the layout and the kernels it was made from: its metadata records
-PACK_LAYOUT_VERSION, the stamp of the kernel sources the packing kernels were built from (unimedvl_amd/lib/build.stamp), the
+PACK_LAYOUT_VERSION, the sha256 of the packing kernels' source (csrc/pack.hip - not of the GEMM / attention / vision kernels, whose
+edits do not change an image), the
 weight / activation dtypes, (name, size, mtime) of every source file and the number of tensors / payload bytes written; on the
 hit path every linear's (N, K) and every tensor's shape are checked against the model's shape table (shapes.all_shapes) and
 every packed image against the size its (N, K) implies.  Anything else means "rebuild and overwrite".  Writing is best effort
@@ -27,12 +28,15 @@ _LIN_FIELDS = ("wp", "bias", "w8", "scale", "w8m")
 
 
 def kernel_stamp():
-    """sha256 of the kernel sources + build flags the loaded library was built from (unimedvl_amd/build.py); "unknown" without one"""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "build.stamp")
+    """sha256 of PACK_LAYOUT_VERSION + the source of the packing kernels (csrc/pack.hip); None when the source is not there - a cache
+    whose maker cannot be identified is never trusted (and two unknowns never compare equal)"""
+    import hashlib
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "pack.hip")
     try:
-        return open(p).read().strip() or "unknown"
+        with open(p, "rb") as f:
+            return hashlib.sha256(PACK_LAYOUT_VERSION.encode() + f.read()).hexdigest()
     except OSError:
-        return "unknown"
+        return None
 
 
 def source_fingerprint(paths):
@@ -73,11 +77,12 @@ class PackStore:
                     self.status = f"other dtypes ({md.get('dtype_tag')} != {dtype_tag})"
                 elif md.get("source") != self.fingerprint:
                     self.status = "made from other checkpoint files"
-                elif md.get("kernel_stamp") != self.kstamp:
-                    self.status = "made by other kernel sources"
+                elif self.kstamp is None or md.get("kernel_stamp") != self.kstamp:
+                    self.status = "made by other (or unidentifiable) packing kernels"
                 else:
                     keys = set(f.keys())
-                    header = int.from_bytes(open(path, "rb").read(8), "little")
+                    with open(path, "rb") as fh:
+                        header = int.from_bytes(fh.read(8), "little")
                     if int(md.get("n_tensors", -1)) != len(keys) or 8 + header + int(md.get("payload_bytes", -1)) != os.path.getsize(path):
                         self.status = "incomplete file (tensor count / payload size differ from what was written)"
                     else:
@@ -167,7 +172,9 @@ class PackStore:
         """Write what the miss path collected (no-op on the hit path / when disabled).  Returns the seconds spent, or None."""
         if self.reading or self.status == "disabled" or not (self.pending or self.pending_lin):
             return None
-        if int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")) or 0) != 0:     # one writer per node: the ranks build identical files
+        # one writer per NODE (the ranks build identical files): LOCAL_RANK decides; a launcher that sets only RANK gives no node-local
+        # information, so every rank writes (the private temporary name + rename keep that safe, and every node ends up with its file)
+        if int(os.environ.get("LOCAL_RANK", "0") or 0) != 0:
             self.status = "not written (local rank 0 writes)"
             self.pending, self.pending_lin = {}, {}
             return None
@@ -186,7 +193,7 @@ class PackStore:
             tensors = {k: v.detach().to("cpu").contiguous() for k, v in self.pending.items()}
             payload = sum(v.numel() * v.element_size() for v in tensors.values())
             save_file(tensors, tmp, metadata=dict(layout_version=PACK_LAYOUT_VERSION, dtype_tag=self.dtype_tag, source=self.fingerprint,
-                                                  kernel_stamp=self.kstamp, n_tensors=str(len(tensors)), payload_bytes=str(payload),
+                                                  kernel_stamp=self.kstamp or "", n_tensors=str(len(tensors)), payload_bytes=str(payload),
                                                   linears=json.dumps(pending_meta)))
             fd = os.open(tmp, os.O_RDONLY)
             try:
