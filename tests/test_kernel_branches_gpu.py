@@ -343,7 +343,7 @@ for M, N, K in ((2048, 4608, 3584), (1000, 1152, 1160), (300, 520, 1096), (700, 
     o3 = torch.full((T, N + 8), 5.0, dtype=BF16, device='cuda')       # output rows wider than N: columns N.. must stay untouched
     ops.gemm(xs, lin_nb, out=o3[:, :N], M=M, row_idx=rows)
     print('sha rows pitched', M, N, K, sha(o3))
-for I, K, M in ((1024, 2048, 2050), (520, 1152, 300)):
+for I, K, M in ((1024, 2048, 2050), (528, 1152, 300)):
     g, u = rnd((I, K), 6, 0.02), rnd((I, K), 7, 0.02)
     lin = ops.PackedLinear.from_gate_up(g, u)
     x = rnd((M, K), 8)

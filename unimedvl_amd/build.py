@@ -25,6 +25,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 FILE_FLAGS = {"attention_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # UMV_GEMM_ABLATIONS=1: also instantiate the tiled GEMM's timing-only ablations and its 32x32x16 variant (UMV_GEMM_TILE=966x / 566...,
 # tools/r04_gemm_abl.sh); never in the default build
+if os.environ.get("UMV_ATTN_TRACE", "0") not in ("0", ""):      # timing study of the prefill attention (tools/attn_trace.py); never in the default build
+    FILE_FLAGS["attention_prefill.hip"] = FILE_FLAGS["attention_prefill.hip"] + ["-DUMV_ATTN_TRACE"]
 if os.environ.get("UMV_GEMM_ABLATIONS", "0") not in ("0", ""):
     FILE_FLAGS["gemm.hip"] = ["-DUMV_GEMM_ABLATIONS"]
     FILE_FLAGS["gemm_w4.hip"] = ["-DUMV_GEMM_ABLATIONS"]

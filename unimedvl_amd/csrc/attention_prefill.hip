@@ -123,11 +123,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
         for (int dt = 0; dt < DT; ++dt) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+#ifdef UMV_ATTN_TRACE       // timing study (UMV_ATTN_TRACE=1 python -m unimedvl_amd.build; tools/attn_trace.py): s_memtime stamps per stage -> a.workspace
+#define ATTN_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(t)); __builtin_amdgcn_sched_barrier(0); } while (0)
+    uint64_t ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+#else
+#define ATTN_STAMP(t) do { } while (0)
+#endif
     stage(0, 0);
     for (int sidx = 0; sidx < nstages; ++sidx) {
+        ATTN_STAMP(ts0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my part of stage sidx has landed
         UMV_BARRIER();                            // ... everyone's; and everyone is done with stage sidx-1
         if (sidx + 1 < nstages) stage(sidx + 1, (sidx + 1) & 1); // overlaps the math below
+        ATTN_STAMP(ts1);
         const char* sb = smem + (sidx & 1) * STAGE;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
 #pragma unroll
                     for (int u = 0; u < TQ; ++u) st[u][t] = mfma16(kf, qf[u][ks], st[u][t]);
                 }
+            ATTN_STAMP(ts2);
             bf16x8 pf[TQ];
             float alpha[TQ];
             bool rescale = false;
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
             // Every MFMA is the builtin; the file is compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py), which keeps all
             // MFMA destinations in VGPRs: by default the compiler parks the 64 O accumulators in AGPRs and moves them out and
             // back around every rescale (PMC then: 15 VALU instructions per MFMA).  Hazards and waits are the compiler's.
+            ATTN_STAMP(ts3);
             constexpr int H0 = (DT + 1) / 2;      // V^T fragments in two halves: half the registers, the second half's reads fly
             const bool tail = kb + 32 > Lk;       // behind the first half's MFMAs.  tail: the last, partial block of the segment
             const int nvalid = min(8, max(0, Lk - (kb + g * 8)));
@@ -235,6 +245,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
 #pragma unroll
                 for (int u = 0; u < TQ; ++u) o[u][dt] = mfma16(vfb[dt - H0], pf[u], o[u][dt]);
         }
+#ifdef UMV_ATTN_TRACE
+        ATTN_STAMP(ts4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts0), "+s"(ts1), "+s"(ts2), "+s"(ts3), "+s"(ts4)::"memory");
+        if (a.workspace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && sidx >= 4 && sidx < 20 && lane == 0) {
+            uint64_t* tr = reinterpret_cast<uint64_t*>(a.workspace) + ((blockIdx.x * 4 + wave) * 16 + (sidx - 4)) * 5;
+            tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts4;
+        }
+#endif
     }
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {

@@ -1432,6 +1432,9 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         return two ? launch_skinny<4, 2, 2, false, 0>(a, KT, NTT, s) : launch_skinny<4, 1, 4, false, 0>(a, KT, NTT, s);
     }
     int cfg = umv_gemm_tile_config(a.M, a.N, a.K);
+    // SwiGLU pairs the gate / up tiles (2p, 2p + 1) INSIDE a wave's column range: the 288-column tile gives a wave 9 tiles, its pairs
+    // would straddle two waves.  (The policy can pick 288 for N = 2 I = k * 288; the model's 37888 is not one of those.)
+    if ((a.epilogue & UMV_EPI_SWIGLU) && cfg == 288) cfg = 384;
     {   // the staging variant of the interleaved tiles: full-line x staging (SCHED = 3) unless UMV_GEMM_XLINE=0 (A/B, tuning only).
         // Bit-identical results; end to end on MI355X (tools/stage_profile.py, same box): text-to-image 1530 -> 1443 ms per batch of 4,
         // prefill of 8 images 131.7 -> 130.7 ms, ViT tower 12.70 -> 12.50 ms.  (A 20-launch microbenchmark from a cold chip shows the
