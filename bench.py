@@ -811,6 +811,7 @@ def main():
                 f"(visible: {torch.cuda.device_count()}), MASTER_ADDR=127.0.0.1; UMV_BENCH_BACKEND=gloo runs the same flow over TCP.")
         dist = Comm(tdist, backend, dev)
 
+    from unimedvl_amd import _lib as _lib_mod
     from unimedvl_amd import ops
     from unimedvl_amd.bagel import Bagel
     from unimedvl_amd.config import UniMedVLConfig
@@ -1009,6 +1010,50 @@ def main():
             e["share_of_profiled_busy_cycles"] = round(b / tot, 3)
         return {"kernels": [e for _, e in ent[:4]],
                 "source": "profiles/roofline_profile_latest.json (rocprofv3 --pmc, one pass per counter set, same kernel sources as this library)"}
+    def mfma_roofline(stage, M, N, K, swiglu, what, reps=20):
+        """`roofline` object of an MFMA-bound leg: its dominant kernel - the tiled GEMM at the leg's biggest shape - timed LIVE with HIP
+        events over `reps` back-to-back launches on the launch stream (sustained clock), flops = 2 M N K per launch, peak = the dense bf16
+        MFMA rate; next to it the average of the same kernel INSIDE the leg from the stamped rocprofv3 kernel trace
+        (profiles/roofline_profile_latest.json `stage_kernels`, matched by kernel family and grid size) when that profile is this library's."""
+        lib = _lib_mod.load()
+        cfgt = int(lib.umv_gemm_tile_config(M, N, K))
+        bn, bm = {266: (256, 256), 268: (256, 128), 384: (384, 128), 288: (288, 128), 270: (128, 128)}.get(cfgt, (128, 64))
+        w4 = K >= 2048 and cfgt in (266, 268, 384) and os.environ.get("UMV_GEMM_W4", "1") != "0"
+        threads = 256 if (w4 or cfgt in (270, 64)) else 512
+        grid = ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * threads
+        g = torch.Generator(device=dev).manual_seed(7)
+        xx = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+        if swiglu:
+            wg = (torch.randn((N // 2, K), device=dev, generator=g) * 0.02).to(torch.bfloat16)
+            lin = ops.PackedLinear.from_gate_up(wg, wg)
+            del wg
+        else:
+            lin = ops.PackedLinear.from_weight((torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.bfloat16))
+        oo = torch.empty((M, N // 2 if swiglu else N), dtype=torch.bfloat16, device=dev)
+        for _ in range(3):
+            ops.gemm(xx, lin, out=oo)
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for _ in range(reps):
+            ops.gemm(xx, lin, out=oo)
+        r1.record()
+        torch.cuda.synchronize()
+        us = r0.elapsed_time(r1) * 1e3 / reps
+        del xx, lin, oo
+        fl = 2.0 * M * N * K
+        ent = {"bound": "mfma", "kernel": f"{'gemm_w4 (4-wave AGPR tile)' if w4 else 'gemm_tiled (8-wave tile)'} {bn}(n) x {bm}(m), {what}",
+               "shape_m_n_k": [M, N, K], "flops_per_launch": fl, "avg_launch_us": round(us, 2), "avg_launch_us_source": f"live, HIP events over {reps} back-to-back launches",
+               "achieved": round(fl / us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / 2500.0, 4), "traffic": None}
+        rows = (prof or {}).get("stage_kernels", {}).get(stage) or []
+        for r in rows:
+            if ("gemm_w4" in r["name"] or "gemm_tiled" in r["name"]) and int(r["grid"]) == grid:
+                ent["avg_launch_us_in_leg"] = round(r["avg_us"], 2)
+                ent["frac_in_leg"] = round(fl / r["avg_us"] / 1e6 / 2500.0, 4)
+                ent["share_of_leg_gpu_time"] = round(r["total_ms"] / max(sum(q["total_ms"] for q in rows), 1e-9), 3)
+                ent["in_leg_source"] = "profiles/roofline_profile_latest.json stage_kernels (rocprofv3 --kernel-trace of tools/stage_profile.py, same kernel sources)"
+                break
+        return ent
     dom_sub = "gemm_skinny_kernelILi1ELi2ELi4E"
     dom = prof_kernel(dom_sub)
     avg_us_replay = avg_us
@@ -1096,6 +1141,7 @@ def main():
     vit = vit_leg(images) if args.config == "full" and not args.no_vit else None
     if vit is not None:
         vit["mfma_counters"] = stage_counters("vit")
+        vit["roofline"] = mfma_roofline("vit", B * (img_hw // cfg.patch) ** 2, cfg.vit_inter, cfg.vit_hidden, False, "SigLIP fc1 (bias + GELU epilogue not in the timed call)")
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
@@ -1185,12 +1231,16 @@ def main():
         if args.config == "full":
             out["t2i"] = run_t2i(model, cfg, dev, rank, world, dist, num_timesteps=args.t2i_steps)
             out["t2i"]["mfma_counters"] = stage_counters("t2i")
+            out["t2i"]["roofline"] = mfma_roofline("t2i", 2 * out["t2i"]["batch_per_gpu"] * 256, 2 * cfg.inter, cfg.hidden, True, "gen-expert gate/up of a guided flow pass (2 contexts x batch x 256 latent tokens)")
             out["prefill_mfma_counters"] = stage_counters("prefill")
+            out["prefill_roofline"] = mfma_roofline("prefill", B * ((img_hw // cfg.patch) ** 2 + 2), 2 * cfg.inter, cfg.hidden, True, "und-expert gate/up of the image-span prefill")
             if not args.no_edit:
                 torch.cuda.empty_cache()
                 try:
                     out["edit"] = run_edit(model, cfg, dev, rank, world, dist, num_timesteps=args.t2i_steps)
                     out["edit"]["mfma_counters"] = stage_counters("edit")
+                    out["edit"]["roofline"] = mfma_roofline("edit", 3 * out["edit"]["batch_per_gpu"] * 1024, 2 * cfg.inter, cfg.hidden, True,
+                                                            "gen-expert gate/up of a guided edit step (3 contexts x batch x 1024 latent tokens)")
                 except Exception as e:      # an extra leg must never take the bench line down
                     if dist is not None:
                         raise

@@ -767,3 +767,62 @@ def test_configs4_mixed_fullwidth(fw):
     assert worst <= 0.9 and allv.mean().item() <= 0.08, f"W8A8 latents: max {worst} mean {allv.mean().item()}"
     del m8
     torch.cuda.empty_cache()
+
+
+def test_continuous_batcher_fullwidth_against_the_oracle(fw):
+    """serving.ContinuousBatcher checked against the ORACLE directly (not against Bagel.chat on the same HIP path): 7 ragged requests -
+    448 x 448 / 224 x 336 / 224 x 224 images or none, 7..40-token prompts, budgets of 3..8 new tokens - on 3 slots at the 14B widths
+    (2 layers), slots reserved for 256 tokens so that the first image request doubles the slabs (twice) while other slots hold
+    live contexts, and four requests are admitted into slots freed in flight.  Per request the oracle rebuilds the context
+    (update_vit / update_text, bagel.py:377-615) and replays the engine's tokens one step at a time (bagel.py:1262-1314, B = 1):
+    every engine token must be the oracle's argmax, or lie within 0.25 of it in the oracle's own logits (teacher forcing where
+    the reference's top-2 margin is inside the logit tolerance); an answer shorter than its budget must end where the oracle
+    (within the same margin) predicts <|im_end|>."""
+    import re
+    from oracle.toy_tokenizer import ToyTokenizer
+    from oracle.unimedvl_cpu import KVCache
+    from unimedvl_amd.serving import ContinuousBatcher
+    model, vae, oracle, cfg, ntid = fw
+    tok = ToyTokenizer(ntid)
+    names = {v: k for k, v in tok.names.items()}
+    sizes = [(224, 224), None, (448, 448), (224, 336), None, (336, 224), (224, 224)]
+    plens, budgets = [12, 40, 32, 7, 25, 18, 9], [6, 4, 8, 5, 7, 3, 6]
+    prompts = _prompts(plens, 811)
+    images = [None if sz is None else _synth_image(sz[0], sz[1], 820 + i) for i, sz in enumerate(sizes)]
+    ident = lambda x: x   # noqa: E731
+    srv = ContinuousBatcher(model, tok, ntid, ident, slots=3, max_context=16, max_new_tokens=8, check_every=3, use_graph=True)
+    cap0 = srv.cache.cap
+    rids = [srv.submit([] if im is None else [im], " ".join(str(t) for t in p), max_new_tokens=nb) for im, p, nb in zip(images, prompts, budgets)]
+    got = srv.run()
+    assert sorted(got) == sorted(rids) and srv.stats["prefills"] == 7
+    assert cap0 == 256 and srv.stats["cache_grows"] >= 2 and srv.cache.cap >= 1024, (cap0, srv.stats, srv.cache.cap)
+    bos, eos = ntid["bos_token_id"], ntid["eos_token_id"]
+    sure = flips = 0
+    worst_margin = 0.0
+    for rid, im, p, nb in zip(rids, images, prompts, budgets):
+        ids = [names[w] if w in names else int(w) for w in re.findall(r"<\|[a-z_]+\|>|-?\d+", got[rid])]
+        assert len(ids) <= nb, (rid, ids, nb)
+        oc = KVCache(cfg.layers, 1)
+        kv, rp = [0], [0]
+        if im is not None:
+            kv, rp = oracle.update_vit(oc, kv, rp, [im], ntid)
+        kv, rp = oracle.update_text(oc, kv, rp, [[bos] + p + [eos]])
+        pos = torch.tensor(rp, dtype=torch.long)
+        fed = bos
+        expect = ids + ([eos] if len(ids) < nb else [])      # a short answer must have ended on <|im_end|>
+        for s, t in enumerate(expect):
+            h = oracle.llm_forward(oracle.embed(torch.tensor([fed])), [1], pos, oc, True, True, "und")
+            ref = oracle.lm_head(h).float()[0]
+            pos = pos + 1
+            top = int(ref.argmax())
+            if top == t:
+                sure += 1
+            else:
+                margin = float(ref[top] - ref[t])
+                worst_margin = max(worst_margin, margin)
+                assert margin <= 0.25, f"request {rid} step {s}: engine token {t}, oracle argmax {top}, margin {margin:.3f}"
+                flips += 1
+            fed = t
+    print(f"continuous batcher vs oracle: {sure} tokens equal to the oracle's argmax, {flips} inside the 0.25 margin (largest {worst_margin:.3f}); "
+          f"slabs {cap0} -> {srv.cache.cap} tokens per slot in {srv.stats['cache_grows']} doublings")
+    assert sure >= 25 and flips <= 3

@@ -22,6 +22,14 @@ done
 # MFMA-bound legs: counters of the dominant kernels of the ViT tower, the image-span prefill and the text-to-image leg
 # (one rocprofv3 pass per counter set, --kernel-trace only), attached by bench.py to its vit_encode / t2i objects
 if [ -z "$SKIP_STAGE_PMC" ]; then
+# per-leg kernel trace (no counters): average duration of every kernel INSIDE the leg, one row per (kernel, grid) = per GEMM shape
+for ST in vit prefill t2i edit; do
+  D=gpurun_out/$TAG/trace_${ST}
+  mkdir -p $D
+  REPS=5 STEPS=12 rocprofv3 --kernel-trace --stats -d $D -o stage -- python tools/stage_profile.py $ST > $D/log.txt 2>&1 || true
+  DBS=$(ls $D/*results.db 2>/dev/null | head -1)
+  [ -n "$DBS" ] && BY_GRID=1 python tools/rocpd_stats.py "$DBS" gpurun_out/${TAG}_${ST}_kernel_stats_by_grid.csv
+done
 for ST in vit prefill t2i edit; do
   for C in "MfmaUtil" "LdsUtil" "SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"; do
     D=gpurun_out/$TAG/stage_${ST}_$(echo $C | tr ' ' '_')
@@ -51,6 +59,14 @@ for st in ("vit", "prefill", "t2i", "edit"):
         except Exception as e:
             rows["error"] = str(e)
     stage_pmc[st] = rows
+stage_kernels = {}
+for st in ("vit", "prefill", "t2i", "edit"):
+    try:
+        rows = list(csv.DictReader(open(f"gpurun_out/{tag}_{st}_kernel_stats_by_grid.csv")))
+    except OSError:
+        continue
+    stage_kernels[st] = [dict(name=r["Name"], grid=int(r["GridX"]), calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
+                              total_ms=int(r["TotalDurationNs"]) / 1e6) for r in rows[:24]]
 stamp = open("unimedvl_amd/lib/build.stamp").read().strip()
 kern = {}
 for r in csv.DictReader(open(f"gpurun_out/{tag}_decode_kernel_stats.csv")):
@@ -73,7 +89,7 @@ try:
     line = json.loads(open(f"gpurun_out/{tag}_decode_line_under_rocprof.json").read().strip().splitlines()[-1])
 except Exception:
     pass
-out = dict(code_stamp=stamp, tag=tag, kernels=kern, pmc=pmc, stage_pmc=stage_pmc,
+out = dict(code_stamp=stamp, tag=tag, kernels=kern, pmc=pmc, stage_pmc=stage_pmc, stage_kernels=stage_kernels,
            bench_line_under_rocprof={k: line.get(k) for k in ("value", "ms_per_step", "steps", "config")},
            correction="traffic = FETCH_SIZE (KiB) x 1024 x 2: gfx950's rocprofv3 tallies the 128-byte requests of a 16 B/lane coalesced stream at 64 B "
                       "(MI355X_MICROARCH.md 'HBM'); WRITE_SIZE is uncalibrated and reported raw (KiB)",

@@ -132,35 +132,16 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
         }
         // lane (row j, g) now holds scores of keys kb + g*8 + t*4 + r
         float sc[8];
-        float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kb + g * 8 + t * 4 + r;
-                float v = st[t][r] * scale_log2e;
-                v = (key <= limit && key < kb_end) ? v : -INFINITY;
-                sc[t * 4 + r] = v;
-                mx = fmaxf(mx, v);
+                sc[t * 4 + r] = (key <= limit && key < kb_end) ? st[t][r] : -INFINITY;
             }
-        mx = xor16_max(mx);
-        mx = xor32_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
-        float ps = 0.f;
+        float alpha;
         bf16x8 pf;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float p = umv_exp2(sc[i] - m_use);   // exp2(-inf) = 0
-            bf16_t pb = f2bf(p);
-            ps += p;
-            pf[i] = (short)pb;
-        }
-        ps = xor16_sum(ps);
-        ps = xor32_sum(ps);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
+        attn_softmax_block(sc, scale_log2e, m_run, l_run, alpha, pf);      // (shared with attn_prefill_kernel: same bits)
         // ---- O^T += V^T P^T ; A = V^T[d = dt*16 + (lane&15)][kb + g*8 .. +8]
         const bool partial = kb + 32 > Lk;
         const int nvalid = min(8, max(0, Lk - (kb + g * 8)));

@@ -11,13 +11,21 @@
 //   * a fragment read from LDS feeds TQ MFMAs (one per q-tile of the wave): half the LDS bytes per flop at TQ = 2;
 //   * interior blocks skip the per-element causal / length masks, and the O rescale is skipped once the running maxima
 //     have settled (alpha == 1 in every lane) - both exact.
-// Per row the arithmetic and its order are those of attn_kernel: results are bit-identical (tools/attn_ab.py).
+// Per row the arithmetic and its order are those of attn_kernel (both call common.h::attn_softmax_block): results are bit-identical
+// (tools/attn_ab.py, tests/test_kernel_branches_gpu.py::test_attn_kernel_variants_bit_identical).
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 #include <stdlib.h>
 #include <type_traits>
 
-__device__ __attribute__((aligned(16))) const uint32_t g_attn_zero_page[4] = {0, 0, 0, 0};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_attn(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for_attn<B + 1, E>(f);
+    }
+}
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 
 // 32-key blocks per LDS stage and the occupancy asked of the register allocator.  The kernel is latency bound (every wave runs
@@ -91,25 +99,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
     const int64_t kstride = a.k_key_stride ? a.k_key_stride : HD;     // packed K (k_key_stride > 0): rows cu_q[s] .. of a [T, ...] buffer
     const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : s * a.k_seg_stride) + kh * a.k_head_stride;
     const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero_page);
-    const int cap = (int)a.v_d_stride;
 
+    // ---- staging: fragment f of a stage (K fragments (t, ks) of its 32-key blocks, then their V^T fragments) is fetched by wave f % 4
+    // with ONE buffer_load_dwordx4 ... lds: the lane's byte offset inside this (segment, kv head)'s K rows / V^T rows is a kernel
+    // constant, the stage advances a scalar offset, and everything outside the data - keys beyond Lk, the d >= HD lanes of a padded
+    // fragment, the end of the V^T rows - is answered with zeros by the buffer's range check (round 5: the per-fragment 64-bit
+    // address arithmetic of the global_load form was ~100 of the ~300 VALU instructions a wave issued per stage, and the kernel is
+    // VALU-issue bound: profiles/r05_attn_stage_trace.txt).  V^T columns in [Lk, cap) may hold stale values: the tail mask below
+    // zeroes them (as before); a fragment that runs past the end of a V^T row reads the next row's head - keys >= Lk, masked too.
+    constexpr int NFR = (NB * FB + 3) / 4;         // fragments per wave and stage
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0,
+                                                                         (int)min((int64_t)Lk * kstride * 2, (int64_t)0x7FFFFFFF), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0,
+                                                                         (int)min((int64_t)HD * a.v_d_stride * 2, (int64_t)0x7FFFFFFF), 0x00020000);
+    uint32_t voff[NFR];
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) {
+        const int f = wave + 4 * i;                // (wave-uniform)
+        const int ff = f % FB;
+        if (ff < FK) {         // K fragment (t, ks): row i of tile t <-> key kb + (i>>2)*8 + t*4 + (i&3)
+            const int t = ff / KS, ks = ff - t * KS;
+            const int d = ks * 32 + g * 8;
+            voff[i] = d < HD ? (uint32_t)((((j >> 2) * 8 + t * 4 + (j & 3)) * kstride + d) * 2) : 0x80000000u;
+        } else {               // V^T fragment dt: row d = dt*16 + j, keys kb + g*8 .. +8
+            const int d = (ff - FK) * 16 + j;
+            voff[i] = d < HD ? (uint32_t)(((int64_t)d * a.v_d_stride + g * 8) * 2) : 0x80000000u;
+        }
+    }
+    const uint32_t kstep = (uint32_t)(32 * kstride * 2);            // bytes per 32-key block of K rows
     auto stage = [&](int sidx, int buf) {
-        for (int f = wave; f < NB * FB; f += 4) {
-            const int b = f / FB, ff = f - b * FB;
-            const int kb = (sidx * NB + b) * 32;
-            const bf16_t* p;
-            if (ff < FK) {     // K fragment (t, ks): row i of tile t <-> key kb + (i>>2)*8 + t*4 + (i&3)
-                const int t = ff / KS, ks = ff - t * KS;
-                const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-                const int d = ks * 32 + g * 8;
-                p = (d < HD) ? kbase + (int64_t)min(key, Lk - 1) * kstride + d : zero;
-            } else {           // V^T fragment dt: row d = dt*16 + j, keys kb + g*8 .. +8
-                const int d = (ff - FK) * 16 + j;
-                const int col = kb + g * 8;
-                p = (d < HD && col + 8 <= cap) ? vbase + (int64_t)d * a.v_d_stride + col : zero;
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const int f = wave + 4 * i;
+            if (f < NB * FB) {
+                const int b = f / FB, ff = f - b * FB;
+                const uint32_t blk = (uint32_t)(sidx * NB + b);
+                const uint32_t off = voff[i];          // (a local: passing the array element makes the host pass drop the kernel's stub)
+                char* dst = smem + buf * STAGE + f * 1024;
+                if (ff < FK) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (attn_lds_ptr_t)dst, 16, off, blk * kstep, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (attn_lds_ptr_t)dst, 16, off, blk * 64u, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds((const void*)p, (attn_lds_ptr_t)(smem + buf * STAGE + f * 1024), 16, 0, 0);
         }
     };
 
@@ -158,50 +187,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
             bf16x8 pf[TQ];
             float alpha[TQ];
             bool rescale = false;
+            // Online softmax on the RAW scores (common.h::attn_softmax_block, shared with attn_kernel: same bits); the masked form
+            // of a boundary block is a code path of its own (merging the two forms after the masks cost the interior path 12
+            // register copies per tile).
+            auto softmax_tile = [&](auto U, auto MASKED) {
+                constexpr int u = decltype(U)::value;
+                constexpr bool masked = decltype(MASKED)::value;
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < TQ; ++u) {
-                float sc[8];
-                float mx = -INFINITY;
-                const bool interior = kb + 32 <= my_end[u] && kb + 31 <= min_limit[u];   // wave uniform
-                if (interior) {
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = st[u][t][r] * scale_log2e;
-                            sc[t * 4 + r] = v;
-                            mx = fmaxf(mx, v);
-                        }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r) {
+                        v[t * 4 + r] = st[u][t][r];
+                        if constexpr (masked) {
                             const int key = kb + g * 8 + t * 4 + r;
-                            float v = st[u][t][r] * scale_log2e;
-                            v = (key <= limit[u] && key < my_end[u]) ? v : -INFINITY;
-                            sc[t * 4 + r] = v;
-                            mx = fmaxf(mx, v);
+                            v[t * 4 + r] = (key <= limit[u] && key < my_end[u]) ? v[t * 4 + r] : -INFINITY;
                         }
-                }
-                mx = xor16_max(mx);     // the 4 lanes (g = 0..3) that hold the row's 32 scores
-                mx = xor32_max(mx);
-                const float m_new = fmaxf(m_run[u], mx);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                alpha[u] = (m_run[u] == -INFINITY) ? 0.f : umv_exp2(m_run[u] - m_use);
-                float ps = 0.f;
+                    }
+                attn_softmax_block(v, scale_log2e, m_run[u], l_run[u], alpha[u], pf[u]);
+            };
+            // both tiles of the wave in ONE basic block per form: the two softmax chains are independent, and side by side the
+            // scheduler interleaves them (a branch per tile left each chain's ~25-deep dependency latency exposed: the stage trace
+            // showed 1200 cycles for ~90 instructions)
+            bool all_interior = true;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float p = umv_exp2(sc[i] - m_use);   // exp2(-inf) = 0
-                    ps += p;
-                    pf[u][i] = (short)f2bf(p);
-                }
-                ps = xor16_sum(ps);
-                ps = xor32_sum(ps);
-                l_run[u] = l_run[u] * alpha[u] + ps;
-                m_run[u] = m_new;
-                rescale = rescale || __any(alpha[u] != 1.0f);
+            for (int u = 0; u < TQ; ++u) all_interior = all_interior && (kb + 32 <= my_end[u] && kb + 31 <= min_limit[u]);   // wave uniform
+            if (all_interior) {
+                if constexpr (TQ == 2) attn_mfma_guard(st[0][0], st[0][1], st[1][0], st[1][1]);      // raw accumulators go to asm maxima (common.h)
+                else attn_mfma_guard(st[0][0], st[0][1]);
+                static_for_attn<0, TQ>([&](auto U) { softmax_tile(U, std::false_type{}); });
             }
+            else static_for_attn<0, TQ>([&](auto U) { softmax_tile(U, std::true_type{}); });
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) rescale = rescale || __any(alpha[u] != 1.0f);
             // ---- O^T += V^T P^T : one V^T fragment from LDS feeds the TQ tiles
             // Straight-line code: the rescale and the tail mask are hoisted out of the dt loop as wave-uniform branches, so the
             // fragment reads are in flight before the first MFMA (with the branches inside the loop every fragment was a

@@ -97,6 +97,59 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ----------------------------------------------------------------------------- one online-softmax block of the attention kernels
+// A lane holds 8 scores of one query row (keys kb + g*8 .. +7 of a 32-key block, masked ones = -inf), RAW (unscaled); the row's 32 scores
+// sit in the 4 lanes l, l^16, l^32, l^48.  c = softmax scale * log2(e) rides in the exponent's fma: p = 2^(s c - m), m = (max s) c.  attn_kernel (attention.hip: decode / short prefill) and attn_prefill_kernel (attention_prefill.hip) both call THIS function,
+// so a row's arithmetic - and its bits - do not depend on which kernel a batch shape is sent to.  (Round 5 form: two values per VALU
+// instruction where the ISA has the packed op, a tree for the row sum, maxima as asm - fmaxf() on MFMA results costs a canonicalising
+// v_max_f32 x, x per operand.)
+typedef float umv_f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float umv_max2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float umv_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// HAZARD: the first consumers of the scores are inline-asm maxima, and the compiler's hazard recogniser covers MFMA-write -> VALU-read only
+// for instructions it knows as VALU, not for inline asm (a v_max3 issued 2 cycles behind the last QK^T MFMA read a stale accumulator: a
+// slightly low row maximum - results still accurate, the softmax is shift invariant, but no longer the bits of the other kernel).  A caller
+// that passes MFMA results untouched (no compiler-visible VALU instruction in between, e.g. a mask select) must tie them to the wait
+// states by hand first: attn_mfma_guard.
+__device__ __forceinline__ void attn_mfma_guard(f32x4& a, f32x4& b) { asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void attn_mfma_guard(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void attn_softmax_block(const float (&v)[8], float c, float& m_run, float& l_run, float& alpha, bf16x8& pf) {
+    float mx = umv_max3(v[0], v[1], v[2]);
+    mx = umv_max3(mx, v[3], v[4]);
+    mx = umv_max3(mx, v[5], v[6]);
+    mx = umv_max2(mx, v[7]);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = umv_max2(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = umv_max2(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    // the running maximum lives in log2 units (m = max s * c): the rescale factor 2^(m_old - m_new) is then EXACTLY 1 whenever the maximum
+    // did not move (an fma on the raw maxima would leave the rounding residue of m c in the exponent: alpha = 1 + 3e-7, and the "nothing
+    // to rescale" test of the prefill kernel would never fire), and the split-KV partials keep their units
+    const float m_new = umv_max2(m_run, mx * c);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float nmc = -m_use;
+    alpha = (m_run == -INFINITY) ? 0.f : umv_exp2(m_run - m_use);
+    const umv_f32x2_v c2 = {c, c}, n2 = {nmc, nmc};
+    umv_f32x2_v pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const umv_f32x2_v e = __builtin_elementwise_fma((umv_f32x2_v){v[2 * i], v[2 * i + 1]}, c2, n2);      // (-inf) c + n = -inf, exp2(-inf) = 0
+        pv[i] = (umv_f32x2_v){umv_exp2(e[0]), umv_exp2(e[1])};
+    }
+    const umv_f32x2_v s2 = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+    float ps = s2[0] + s2[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = pack2bf(pv[i][0], pv[i][1]);
+        pf[2 * i] = (short)(w & 0xFFFFu);
+        pf[2 * i + 1] = (short)(w >> 16);
+    }
+    ps = xor16_sum(ps);
+    ps = xor32_sum(ps);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+}
+
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
