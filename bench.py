@@ -1018,7 +1018,7 @@ def main():
         lib = _lib_mod.load()
         cfgt = int(lib.umv_gemm_tile_config(M, N, K))
         bn, bm = {266: (256, 256), 268: (256, 128), 384: (384, 128), 288: (288, 128), 270: (128, 128)}.get(cfgt, (128, 64))
-        w4 = K >= 2048 and cfgt in (266, 268, 384) and os.environ.get("UMV_GEMM_W4", "1") != "0"
+        w4 = cfgt in (266, 268, 384) and os.environ.get("UMV_GEMM_W4", "1") not in ("0", "3")
         threads = 256 if (w4 or cfgt in (270, 64)) else 512
         grid = ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * threads
         g = torch.Generator(device=dev).manual_seed(7)
@@ -1114,7 +1114,7 @@ def main():
             small.append({"kernel": label, "avg_launch_us": round(v[0], 2), "launches_profiled": v[1]})
 
     # ---- ViT encode (MFMA-bound leg of the prefill): B x 448x448 through the SigLIP tower + connector
-    def vit_leg(images_v, reps=3):
+    def vit_leg(images_v, reps=10):
         Bv = len(images_v)
         gi_v, _, _ = model.prepare_vit_images([0] * Bv, [0] * Bv, images_v, lambda x: x, new_token_ids)
         px = gi_v["packed_vit_tokens"].to(dev)          # the patch tokens, or (device patchify) the images: resident either way

@@ -1,6 +1,6 @@
 // EXPERIMENTAL (libunimedvl_hip_experimental.so): measured and not adopted - a weight that is already resident in the 256 MiB
 // memory-side cache is not delivered faster than HBM delivers it, and a prefetch branch on a second stream made the decode
-// graph slower.
+// graph slower (profiles/HISTORY.md section 5b).
 #include "common.h"
 #include "unimedvl_hip_experimental.h"
 

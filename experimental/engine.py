@@ -10,7 +10,7 @@ with the weight stream of every op already in flight while the previous op's row
 This module only builds the op tables (device memory, read with scalar loads) and owns the counters.
 
 EXPERIMENTAL: bit-identical to the kernel chain (tests/test_decode_engine_gpu.py) but slower on MI355X (116 vs 93 us per layer
-for these ops) - every hand-off between workgroups costs 3-4 loaded memory round trips.  It lives in
+for these ops, profiles/HISTORY.md section 5b) - every hand-off between workgroups costs 3-4 loaded memory round trips.  It lives in
 experimental/lib/libunimedvl_hip_experimental.so and is not wired into decode.py.
 """
 import ctypes as C

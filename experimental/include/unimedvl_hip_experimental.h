@@ -1,6 +1,6 @@
 /*
  * libunimedvl_hip_experimental.so - kernels that were built, checked against the product kernels and MEASURED, but are
- * not on the product path (DESIGN.md section 5b says why each of them lost); kept, with their tests, as the starting
+ * not on the product path (profiles/HISTORY.md section 5b says why each of them lost); kept, with their tests, as the starting
  * point for whoever continues.  Nothing in unimedvl_amd's default path loads this library.  Same conventions as
  * unimedvl_hip.h (device pointers, asynchronous on `stream`, 0 / negative return, message from umv_exp_last_error()).
  */
@@ -126,7 +126,7 @@ int umv_attn_decode_fused(const umv_attn_decode_args* a, umv_stream_t stream);
  * hd = 128 only (flash_attn_varlen_func at qwen2_navit.py:605-614).  One wave owns 32 q columns, K Q^T / softmax / P V of three
  * consecutive key blocks are software-pipelined, K / V^T blocks reach LDS as contiguous 1 KiB LDS-DMA pieces with a source-side
  * swizzle.  Correct (tests/test_attn_prefill32_gpu.py) and as fast as the shipped attn_prefill_kernel, not faster
- * (DESIGN.md section 5b has the counters and the ablation): kept here, not on the product path. */
+ * (profiles/HISTORY.md section 5b has the counters and the ablation): kept here, not on the product path. */
 int umv_attn_prefill32(const umv_attn_args* a, umv_stream_t stream);
 
 /* Stream `bytes` at `ptr` through the cache hierarchy (no compute) so that they are resident in the

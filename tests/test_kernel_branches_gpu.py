@@ -281,8 +281,8 @@ print('sha swiglu', hashlib.sha256(o3.cpu().view(torch.int16).numpy().tobytes())
 
 @pytest.mark.parametrize("tile", [266, 268, 384])
 def test_gemm_w4_bit_identical(ops, tile):
-    """The 4-wave tiles with the accumulators in literal AGPRs (gemm_w4.hip: 256 x 256, 256 x 128, 384 x 128; the default for
-    K >= 2048, UMV_GEMM_W4=2 forces them at every K) against the 8-wave tiles of the same shape (UMV_GEMM_W4=0): the same MFMAs on
+    """The 4-wave tiles with the accumulators in literal AGPRs (gemm_w4.hip: 256 x 256, 256 x 128, 384 x 128; the default at every K since
+    the lean epilogue; UMV_GEMM_W4=2 says so explicitly) against the 8-wave tiles of the same shape (UMV_GEMM_W4=0): the same MFMAs on
     the same operands in the same k order, so every output bit must agree - full tiles, ragged M / N, K % 64 != 0 and K % 32 != 0
     (zero-filled tail chunks), an odd number of k-steps, K shorter than the prologue, fewer k-steps than the unroll period, row-indexed
     A / C, bias + residual, bias + GELU and the SwiGLU epilogue."""

@@ -1,4 +1,4 @@
-// How fast can ONE workgroup per (segment, kv head) stream a decode-attention context?  (the fused
+// How fast can ONE workgroup per (segment, kv head) stream a decode-attention context?  (profiles/HISTORY.md section 5b: the fused
 // workgroup kernel took 33 us at B=8 / 1.1k keys because its MFMA-fragment-direct loads touch 16 cache lines per
 // quarter-wave.)  Two load patterns over the same bytes, same MFMAs, same LDS merge:
 //   mode 0  row-major K [cap][128] and V^T [128][cap] - the slab layout of today

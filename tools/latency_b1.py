@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Single-request latency at full 14B dims (random weights): one 448x448 image + 32-token question -> prefill wall time with
-the eager image span vs the HIP-graph replay into a pooled (reserved) cache, then 16 decode steps.  DESIGN.md section 7.4."""
+the eager image span vs the HIP-graph replay into a pooled (reserved) cache, then 16 decode steps.  profiles/HISTORY.md section 7.4."""
 import os
 import sys
 import time

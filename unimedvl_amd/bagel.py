@@ -103,7 +103,7 @@ class Bagel(BagelPrep):
         h = ops.gemm(vit, self.glue.conn1, act="gelu_tanh")
         return ops.gemm(h, self.glue.conn2)
 
-    # ---- image-span prefill from a HIP graph
+    # ---- image-span prefill from a HIP graph (profiles/HISTORY.md section 7.4)
     # One 448x448 image is ~460 kernel launches (ViT tower, connector, 28 LLM layers over 1026 tokens): 33 ms of GPU work but
     # ~55 ms of wall time when every launch goes through ctypes.  The shapes depend only on the image's patch grid, and all
     # per-request values (pixels, which cache segment / slot the tokens go to, rope position, keys visible) are read by the

@@ -1445,17 +1445,18 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
         if (xline > 1 && cfg == 288) cfg = 388;      // the 288-column tile with full-line staging: measured, not adopted (ablation builds only)
 #endif
     }
-    {   // round 5: the 4-wave tiles with the accumulators in AGPRs (gemm_w4.hip) take over the 8-wave tiles of the same shape on the
-        // LLM's GEMMs (K = 3584 / 18944): bit-identical results (same MFMAs, operands and k order), sustained loops on MI355X
-        // (profiles/r05_w4_policy.txt): gate/up 2048 x 37888 x 3584 458 -> 408 us (1.21 -> 1.36 PF), 8208 rows 1790 -> 1602 us (1.39 PF),
-        // down 2048 x 3584 x 18944 254 -> 205 us (1.36 PF), o_proj 8208 x 3584 x 3584 182 -> 169 us; end to end text-to-image
-        // 1387 -> 1315 ms per batch of 4, prefill of 8 images 123.1 -> 116.5 ms.  NOT at short K: a 256 x 256 tile's fill and its
-        // 256-register epilogue on four waves cost more than the 8-wave tile's at K = 1152 (SigLIP q/k/v 67.8 -> 80.6 us, fc1
-        // 85.8 -> 103.4 us, tower 11.6 -> 12.3 ms with the 4-wave tiles everywhere), so the rule is K >= 2048.
-        // UMV_GEMM_W4=0: the 8-wave tiles everywhere, 2: the 4-wave tiles at every K (A/B, tuning only)
+    {   // round 5: the 4-wave tiles with the accumulators in AGPRs (gemm_w4.hip) take over the 8-wave tiles of the same shape: bit-identical
+        // results (same MFMAs, operands and k order).  Sustained loops on MI355X (profiles/r05_w4_policy.txt): gate/up 2048 x 37888 x 3584
+        // 458 -> 408 us (1.21 -> 1.36 PF), 8208 rows 1790 -> 1602 us (1.39 PF), down 2048 x 3584 x 18944 254 -> 205 us (1.36 PF), o_proj
+        // 8208 x 3584 x 3584 182 -> 169 us; end to end text-to-image 1387 -> 1315 ms per batch of 4, prefill of 8 images 123.1 -> 116.5 ms.
+        // At short K (SigLIP, K = 1152) they first LOST - q/k/v 67.8 -> 80.6 us, tower 11.6 -> 12.3 ms - because the general epilogue's
+        // 35 k cycles per tile ran on four waves instead of eight; with the lean epilogue (gemm_epilogue.h) they win there too: q/k/v
+        // 64.5 -> 59.9 us, fc1 84.9 -> 80.0 us, tower 10.66 -> 10.50 ms at 8 images and 38.0 -> 37.3 ms at 32 (20-repetition runs, twice;
+        // profiles/r05_lean_epilogue.txt).  So: every K.  UMV_GEMM_W4=0: the 8-wave tiles everywhere, 3: the 4-wave tiles only at
+        // K >= 2048 (the rule before the lean epilogue) - A/B, tuning only.
         static const int w4 = umv_env_int("UMV_GEMM_W4", 1);
         const int c4 = cfg == 366 ? 466 : cfg == 368 ? 468 : cfg == 484 ? 4384 : 0;
-        if (w4 && c4 && (w4 == 2 || a.K >= 2048) && umv_gemm_w4_can_take(a, KT, NTT)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
+        if (w4 && c4 && (w4 != 3 || a.K >= 2048) && umv_gemm_w4_can_take(a, KT, NTT)) return umv_gemm_w4_launch(a, KT, NTT, c4, raster_gn(), s);
     }
     if (cfg == 466 || cfg == 468 || cfg == 4384 || cfg == 94661 || cfg == 94662) return umv_gemm_w4_launch(a, KT, NTT, cfg, raster_gn(), s);
     // experimental weight-streaming shapes of the tiled kernel for 16 < M <= 128 (tuning only, UMV_GEMM_TILE + UMV_GEMM_SKINNY_MAX)
@@ -1469,7 +1470,7 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
     if (cfg == 130) return launch_tiled<2, 2, 4, 4, 1, 4>(a, KT, NTT, s);      // 128x128x32, 4 buffers (64 KiB, 2 WG/CU)
     if (cfg == 288) return launch_tiled<2, 4, 9, 2, 1, 4, 1>(a, KT, NTT, s);   // 288(n)x128(m)x32: N = 1152 / 4608 = 4 / 16 x 288 -> 256 tiles at 8192 / 2048 rows
     if (cfg == 266) return launch_tiled<2, 4, 8, 4, 1, 4, 1>(a, KT, NTT, s);   // 256x256x32, 4 buffers, MFMA / ds_read interleaved by hand
-#ifdef UMV_GEMM_ABLATIONS     // measured and not adopted / timing-only variants (UMV_GEMM_ABLATIONS=1 python -m unimedvl_amd.build)
+#ifdef UMV_GEMM_ABLATIONS     // measured and not adopted / timing-only variants (UMV_GEMM_ABLATIONS=1 python -m unimedvl_amd.build; profiles/HISTORY.md section 5b)
     if (cfg == 9661) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 1>(a, KT, NTT, s);   // ablations of 266 (timing only)
     if (cfg == 9662) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 2>(a, KT, NTT, s);
     if (cfg == 9663) return launch_tiled<2, 4, 8, 4, 1, 4, 1 + 16 * 3>(a, KT, NTT, s);

@@ -9,7 +9,7 @@
 //   * a 128 x 128 wave tile needs 16 fragment reads per 64 MFMAs where the 8-wave kernel's 128 x 64 tiles need 12 per 32:
 //     a third less LDS read traffic per flop, half the waves at the barrier, nobody to share the SIMD's matrix pipe with;
 //   * its 256 accumulator registers cannot live in VGPRs next to 2 x 16 fragments, and hipcc (ROCm 7.2) cannot allocate them
-//     through "+a" constraints without spilling into the counted-vmcnt loop.  Here the accumulators
+//     through "+a" constraints without spilling into the counted-vmcnt loop (profiles/HISTORY.md section 5b, round 4).  Here the accumulators
 //     are LITERAL registers a[4i : 4i+3] in the instruction text.  The compiler never sees them: it allocates only the
 //     fragment / address VGPRs, the kernel zeroes a[0:255] itself and moves them out 128 at a time for the epilogue.
 //     (What keeps this sound: the compiler uses AGPRs on its own only to spill, and this kernel's VGPR pressure is < 200 of

@@ -14,7 +14,7 @@ sums that the kernel which follows anyway finishes - the attention kernel (or um
 partials, umv_residual_rmsnorm_bf16 = partial sum + residual add + the next RMSNorm - so a split never
 adds a launch and the summation order stays fixed.
 
-Tried and measured slower on MI355X, no longer wired in here: RMSNorm folded into the next
+Tried and measured slower on MI355X, no longer wired in here (profiles/HISTORY.md section 5b): RMSNorm folded into the next
 GEMM's prologue (norm_w of umv_gemm_bf16: every workgroup pays the normalise + stage latency before its
 first MFMA, step 3.40 -> 3.93 ms) and weight prefetch into the Infinity Cache on a parallel graph branch
 (umv_prefetch: the branch does not overlap under graph replay, 3.43 -> 4.5-5.4 ms).
