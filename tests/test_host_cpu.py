@@ -273,3 +273,42 @@ def test_kernel_policy_queries_need_no_gpu():
     assert lib.umv_attn_prefill_tq(8, 16, 16, 72, 1024) == 2
     assert lib.umv_attn_prefill_tq(8, 28, 4, 128, 1) == 0           # decode: the per-wave kernel
     assert lib.umv_attn_prefill_tq(8, 2, 1, 64, 1000) == 0          # head dims without an LDS-shared kernel
+
+
+def test_w4_kernels_own_their_agprs(tmp_path):
+    """gemm_w4.hip keeps its accumulators in LITERAL AGPRs the compiler never sees.  That is only sound while the compiler does not touch
+    AGPRs on its own while they hold accumulators - and hipcc spills VGPRs INTO AGPRs when a kernel needs more than 256 of them (it happened
+    in an experiment: lane constants of the epilogue hoisted out of a persistent tile loop; results were garbage and piece offsets came back
+    corrupted).  Compile the file to ISA (no GPU needed) and check every kernel: exactly NACC zeroing writes (`v_accvgpr_write_b32 aN, 0`);
+    no compiler spill (`v_accvgpr_write_b32 aN, vM`) before the last MFMA; and none at all in a kernel whose epilogue leaves the AGPRs in
+    more than one chunk (TM > 4: the second chunk's accumulators are still in AGPRs while the first chunk's epilogue runs).  The single-chunk
+    384 x 128 kernel does spill into AGPRs inside its epilogue - after every accumulator has been read out: harmless."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "unimedvl_amd", "csrc", "gemm_w4.hip")
+    out = str(tmp_path / "w4.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc", "-S", "--cuda-device-only",
+                        "-o", out, src], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = open(out).read()
+    names = re.findall(r"^(_Z14gemm_w4_kernel\w+):", s, re.M)
+    assert len(names) >= 6
+    for n in names:
+        a = s.index(n + ":")
+        b = s.index(".Lfunc_end", a)
+        body = s[a:b]
+        m = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", n)
+        tn, tm = int(m.group(3)), int(m.group(4))
+        nacc = tn * tm * 4
+        scratch = int(re.compile(r"; ScratchSize: (\d+)").search(s, b).group(1))
+        zero_writes = len(re.findall(r"v_accvgpr_write_b32 a\[(?:0x[0-9a-f]+|\d+)\], 0\s", body))
+        spills = [mm.start() for mm in re.finditer(r"v_accvgpr_write_b32 a\d+, v\d+", body)]
+        last_mfma = max(mm.start() for mm in re.finditer(r"v_mfma", body))
+        assert zero_writes == nacc, f"{n}: {zero_writes} zeroing writes for {nacc} accumulators"
+        assert all(p > last_mfma for p in spills), f"{n}: the compiler spills into AGPRs while the k loop runs"
+        assert tm <= 4 or not spills, f"{n}: {len(spills)} compiler spills into AGPRs while accumulators of a later epilogue chunk live there"
+        assert scratch == 0 and "v_accvgpr_mov" not in body, f"{n}: scratch {scratch}"

@@ -293,7 +293,8 @@ sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}
 from unimedvl_amd import ops
 from test_kernel_branches_gpu import rnd, BF16
 def sha(t): return hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
-for M, N, K in ((2048, 4608, 3584), (8192, 1152, 4304), (1000, 1152, 1160), (300, 520, 1096), (700, 3584, 96), (515, 1152, 4304), (260, 300, 40), (4099, 777, 2080), (130, 260, 160)):
+for M, N, K in ((2048, 4608, 3584), (8192, 1152, 4304), (1000, 1152, 1160), (300, 520, 1096), (700, 3584, 96), (515, 1152, 4304), (260, 300, 40), (4099, 777, 2080), (130, 260, 160),
+                (4500, 4616, 160), (5000, 6004, 96)):      # > 256 tiles: several rounds of tiles per CU (lean and general epilogue)
     x = rnd((M, K), 1); w = rnd((N, K), 2, 1 / math.sqrt(K)); b = rnd((N,), 3)
     lin = ops.PackedLinear.from_weight(w, b)
     res = rnd((M, N), 4)
@@ -314,7 +315,7 @@ print('sha swiglu', sha(ops.gemm(rnd((2050, 2048), 8), lin)))
         r = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, UMV_GEMM_TILE=str(tile), UMV_GEMM_W4=w4))
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         shas[w4] = [ln for ln in r.stdout.splitlines() if ln.startswith("sha")]
-        assert len(shas[w4]) == 28
+        assert len(shas[w4]) == 34
     assert shas["0"] == shas["2"], [(a, b) for a, b in zip(shas["0"], shas["2"]) if a != b]
 
 

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_w4_kernel(umv_gemm_args a, 
     // epilogue: the accumulators leave the AGPRs 4 m-tiles at a time (TN x 4 x 4 = 128 registers at TN = 8) and go through the
     // wave's own LDS region as whole rows (gemm_epilogue.h); same arithmetic and roundings as the 8-wave tiles
     EpiCtx e{a.bias, a.residual, a.ldr, a.out, a.ldo, a.N, a.epilogue};
-    constexpr int JC = 4;
+    constexpr int JC = TN > 8 ? 2 : 4;      // (TN = 12: 192 live accumulator copies made hipcc spill ~270 registers - into AGPRs - inside the epilogue)
     static_assert(TM % JC == 0, "m-tiles per epilogue chunk");
     char* wreg = smem + wave * (TN * JC * 512);
     static_for<0, TM / JC>([&](auto H) {
