@@ -1146,14 +1146,15 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
     # ---- the reference's DEFAULT decode mode (interactive_vqa_inferencer.py:58-71: do_sample=True, temperature 1.0; bagel.py:1297-1299):
-    # same batch / context, the step ends lm_head -> umv_sample_bf16 (softmax of the logits + inverse-CDF draw on the device) ->
-    # umv_decode_step_end instead of the fused argmax epilogue.  Never the headline value (BASELINE.json's metric is greedy).
+    # same batch / context; the draw is a Gumbel-max over bf16(logit / T) in the lm_head epilogue (umv_gemm_args.sample_temperature), finished by
+    # the same step-end kernel as the greedy step.  Never the headline value (BASELINE.json's metric is greedy).
     sampled = None
     if args.config == "full" and not args.no_sampled and not lw.fp8:
         ls = decode_leg(model, do_sample=True, gather="ids")
         sampled = {"tokens_per_s": round(world * B * args.steps / ls["elapsed"], 2), "ms_per_step": round(ls["elapsed"] * 1e3 / args.steps, 4),
                    "mode": "do_sample=True, temperature=1.0 (the reference's default, interactive_vqa_inferencer.py:58-71)",
-                   "step_tail": "lm_head GEMM -> umv_sample_bf16 -> umv_decode_step_end (3 launches; the greedy step fuses the argmax into the lm_head epilogue: 2)",
+                   "step_tail": "lm_head GEMM with the Gumbel-max keys in its epilogue (sample_temperature) -> umv_decode_step_end_argmax: the greedy step's two "
+                                "launches (round 4 / early round 5: lm_head -> umv_sample_bf16 -> umv_decode_step_end, 3.29 ms per step)",
                    "greedy_ms_per_step": round(ms_per_step, 4)}
         ls = None
         torch.cuda.empty_cache()

@@ -94,6 +94,13 @@ typedef struct {
     int64_t x_rows;           /* with row_idx: number of rows of the buffer `x` points into (rows row_idx may name), 0 = unknown.
                                  The 4-wave tiles of the M > 64 path address x through 32-bit offsets and take a row-indexed call
                                  only when x_rows * ldx * 2 < 2 GiB is known; unknown keeps the 8-wave tiles (same results). */
+    float sample_temperature; /* with argmax_partial, > 0: the keys are those of SAMPLING instead of greedy decoding (bagel.py:1297-1299:
+                                 probs = softmax(logits / temperature), token = multinomial(probs, 1)) by the Gumbel-max rule: the key of
+                                 column n orders bf16(logit / T) - ln(-ln(u)), u uniform in (0, 1] from a counter-based generator
+                                 (splitmix64 of sample_seed, *sample_step, the row and n - the stream of umv_sample_bf16), so the maximum key
+                                 over a row is one draw from the softmax.  0: greedy keys. */
+    uint64_t sample_seed;
+    const int64_t* sample_step; /* device word: the decode step (changes the draw every step under a replayed HIP graph); NULL = 0 */
 } umv_gemm_args;
 int umv_gemm_bf16(const umv_gemm_args* a, umv_stream_t stream);
 /* Host-only query: the tiled-kernel configuration umv_gemm_bf16 picks for an M x N x K problem (0 for M <= 64, the

@@ -212,6 +212,56 @@ def test_sampling_matches_softmax_distribution(ops):
         ops.sample(big, 0.0, seed=1)
 
 
+def test_sampling_in_the_lm_head_epilogue_matches_softmax_distribution(ops):
+    """do_sample fused into the lm_head GEMM (umv_gemm_args.sample_temperature: Gumbel-max over bf16(logit / T), bagel.py:1297-1299):
+    the maximum key of a row must be distributed as softmax(logits / T).  64 rows x 64 steps = 4096 draws from ONE logits vector
+    (x = e_0, so logits = W[:, 0]) against the softmax with a chi-square bound; the same (seed, step) gives the same draw, another step
+    another one; temperature -> 0 is the greedy token; the logits written to `out` are those of the plain GEMM."""
+    import numpy as np
+    V, K, T, rows = 40, 32, 0.7, 64
+    g = torch.Generator().manual_seed(81)
+    w = torch.zeros((V, K))
+    w[:, 0] = torch.randn(V, generator=g) * 2
+    w = w.to(BF16).cuda()
+    lin = ops.PackedLinear.from_weight(w)
+    x = torch.zeros((rows, K), dtype=BF16, device="cuda")
+    x[:, 0] = 1.0
+    logits = w[:, 0].float().cpu()
+    p = torch.softmax((logits / T).to(BF16).float(), -1)
+    keys = torch.zeros((rows, (V + 15) // 16), dtype=torch.int64, device="cuda")
+    out = torch.empty((rows, V), dtype=BF16, device="cuda")
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def draw(seed, s, temp=T):
+        step.fill_(s)
+        keys.zero_()
+        ops.gemm(x, lin, out=out, argmax_partial=keys, sample=(temp, seed, step))
+        k = keys.cpu().numpy().view(np.uint64).max(axis=1)
+        return torch.from_numpy((np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64))
+    counts = torch.zeros(V)
+    for s in range(64):
+        ids = draw(1234, s)
+        assert int(ids.min()) >= 0 and int(ids.max()) < V
+        counts += torch.bincount(ids, minlength=V).float()
+    assert torch.equal(out.float().cpu(), logits.to(BF16).float().expand(rows, V)), "the logits themselves must be the plain GEMM's"
+    n = counts.sum()
+    exp = p * n
+    mask = exp > 5
+    chi2 = (((counts - exp) ** 2) / exp)[mask].sum().item()
+    dof = int(mask.sum()) - 1
+    assert chi2 < dof + 6 * (2 * dof) ** 0.5, f"chi2 {chi2:.1f} for {dof} dof"
+    a, b, c = draw(99, 3), draw(99, 3), draw(99, 4)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert len(set(a.tolist())) > 1, "rows must draw independently"
+    assert (draw(5, 0, temp=0.01) == int(logits.argmax())).all()
+    greedy = torch.zeros_like(keys)
+    ops.gemm(x, lin, out=out, argmax_partial=greedy)
+    kg = greedy.cpu().numpy().view(np.uint64).max(axis=1)
+    assert ((np.uint64(0xFFFFFFFF) - (kg & np.uint64(0xFFFFFFFF))).astype(np.int64) == int(logits.argmax())).all()
+    with pytest.raises(Exception):
+        ops.gemm(x, lin, out=out, sample=(T, 1, step))          # sampling without the key buffer
+
+
 def _rope_tables(max_pos, hd, theta=1e6):
     from oracle.unimedvl_cpu import rope_cos_sin
     return rope_cos_sin(torch.arange(max_pos), hd, theta, BF16)

@@ -19,6 +19,7 @@ class GemmArgs(C.Structure):
         ("row_idx", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
         ("norm_w", C.c_void_p), ("norm_eps", C.c_float), ("tile_rows", C.c_int), ("w_scale", C.c_void_p),
         ("k_splits", C.c_int), ("split_stride", C.c_int64), ("argmax_partial", C.c_void_p), ("x_rows", C.c_int64),
+        ("sample_temperature", C.c_float), ("sample_seed", C.c_uint64), ("sample_step", C.c_void_p),
     ]
 
 

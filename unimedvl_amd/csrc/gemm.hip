@@ -331,7 +331,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(umv_gemm_arg
                 epi_store4(et, orow, n0, s.x, s.y, s.z, s.w, fin);
             }
             if (a.argmax_partial && nt0 + t < NTT)   // wave-uniform: greedy argmax rides on the lm_head epilogue
-                epi_argmax_tile(a.argmax_partial, NTT, m, nt0 + t, l, valid, n0, nend, fin);
+                epi_argmax_tile(a.argmax_partial, NTT, m, nt0 + t, l, valid, n0, nend, fin, a.sample_temperature, a.sample_seed, a.sample_step);
         }
     }
 }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny8_kernel(umv_gemm_ar
                 epi_store4(e, orow, n0, s.x, s.y, s.z, s.w, fin);
             }
             if (a.argmax_partial && nt0 + t < NTT)
-                epi_argmax_tile(a.argmax_partial, NTT, m, nt0 + t, l, valid, n0, a.N, fin);
+                epi_argmax_tile(a.argmax_partial, NTT, m, nt0 + t, l, valid, n0, a.N, fin, a.sample_temperature, a.sample_seed, a.sample_step);
         }
     }
 }
@@ -1369,6 +1369,8 @@ extern "C" int umv_gemm_bf16(const umv_gemm_args* ap, umv_stream_t stream) {
                                     !(a.epilogue & (UMV_EPI_SWIGLU | UMV_EPI_OUT_F32))),
               UMV_ERR_UNSUPPORTED, "gemm: argmax_partial is an epilogue of the decode lm_head GEMM (M <= 64, 16-row image, bf16 out, "
               "no SwiGLU / split-K / row_idx / fused norm)");
+    UMV_CHECK(a.sample_temperature >= 0.f && (a.sample_temperature == 0.f || a.argmax_partial), UMV_ERR_ARG,
+              "gemm: sample_temperature (%g) is a mode of the argmax_partial epilogue and must be >= 0", (double)a.sample_temperature);
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 31) / 32;

@@ -59,14 +59,35 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
 // The lane holds columns n0..n0+3 of row m of tile `tile` (lanes l, l^16, l^32, l^48 share the row): reduce the tile's 16
 // columns and let the first lane group write partial[m][tile].  `final` are the values epi_store4 stored (bf16-exact).
 // Must be called by ALL lanes of the wave (shuffles); lanes without a valid element pass valid = false.
+// Sampling as an argmax (Gumbel-max): with temp > 0 the value whose key is taken is bf16(logit / temp) - ln(-ln(u)), u in (0, 1] from
+// splitmix64(row key + column) - argmax over a row = one draw from softmax(logits / temp) (bagel.py:1297-1299).  The generator and its
+// keying are umv_sample_bf16's (elementwise.hip); u == 1 gives +inf (that column wins), as q == 0 does there.
+__device__ __forceinline__ uint64_t epi_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t epi_sample_row_key(uint64_t seed, const int64_t* step_ptr, int m) {
+    const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : 0ull;
+    return epi_splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull) ^ ((uint64_t)m << 32));
+}
+__device__ __forceinline__ float epi_gumbel_value(float logit, float temp, uint64_t row_key, int n) {
+    const float y = rbf(logit / temp);                                    // logits / temperature is a bf16 tensor in the reference
+    const uint64_t h = epi_splitmix64(row_key + (uint64_t)n);
+    const float u = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+    return y - __logf(-__logf(u));
+}
 __device__ __forceinline__ void epi_argmax_tile(uint64_t* __restrict__ partial, int64_t ld_partial, int m, int tile, int lane, bool valid,
-                                                int n0, int nend, const float* final) {
+                                                int n0, int nend, const float* final, float temp = 0.f, uint64_t seed = 0, const int64_t* step_ptr = nullptr) {
     uint64_t key = 0;
     if (valid) {
+        const uint64_t row_key = temp > 0.f ? epi_sample_row_key(seed, step_ptr, m) : 0ull;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (n0 + j < nend) {
-                const uint64_t kj = argmax_key(final[j], n0 + j);
+                const float v = temp > 0.f ? epi_gumbel_value(final[j], temp, row_key, n0 + j) : final[j];
+                const uint64_t kj = argmax_key(v, n0 + j);
                 key = kj > key ? kj : key;
             }
     }

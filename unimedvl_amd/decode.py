@@ -91,7 +91,9 @@ class DecodeSession:
         self.logits = torch.empty((B, cfg.vocab), dtype=BF16, device=dev)
         # greedy: the argmax rides on the lm_head epilogue (one key per 16-column tile and row) and is finished by the
         # step-end kernel - the separate 25 us argmax launch over the logits is gone (UMV_DECODE_FUSED_ARGMAX=0 restores it)
-        self.fused_argmax = (not do_sample) and B <= 64 and os.environ.get("UMV_DECODE_FUSED_ARGMAX", "1") not in ("0", "")
+        # sampling rides the same way (round 5): the keys order bf16(logit / T) + Gumbel noise, their maximum is one draw from the softmax -
+        # the sampled step has the greedy step's two-launch tail (lm_head -> sample -> step_end was 3.29 ms against 3.12)
+        self.fused_argmax = B <= 64 and os.environ.get("UMV_DECODE_FUSED_ARGMAX", "1") not in ("0", "")
         if self.fused_argmax:
             self.amax_part = torch.zeros((B, (cfg.vocab + 15) // 16), dtype=torch.int64, device=dev)
         w = llm.w
@@ -178,7 +180,8 @@ class DecodeSession:
                 ops.gemm(self.act, down_w, out=self.seq, residual=self.seq)
                 ops.rmsnorm(self.seq, nxt, cfg.rms_eps, out=dst)
         if self.fused_argmax:
-            ops.gemm(self.hn, w.lm_head, out=self.logits, argmax_partial=self.amax_part)
+            ops.gemm(self.hn, w.lm_head, out=self.logits, argmax_partial=self.amax_part,
+                     sample=(self.temperature, self.seed, self.step_idx) if self.do_sample else None)
             # ids = argmax; pred_ids[step] = in_ids[step + 1] = ids; slot / position / kv_len / step += 1: one launch
             ops.decode_step_end_argmax(self.tok_slot, self.tok_pos, self.kv_len, self.amax_part, self.ids, self.in_ids, self.pred_ids,
                                        self.step_idx)

@@ -160,12 +160,14 @@ class PackedLinear:
 
 
 def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out_f32=False, use_bias=True,
-         norm_w=None, norm_eps=1e-6, act8=False, argmax_partial=None):
+         norm_w=None, norm_eps=1e-6, act8=False, argmax_partial=None, sample=None):
     """out = epilogue(x @ W^T).  x [M,K] bf16 (row stride may exceed K).  act in {None,'gelu_tanh','silu'}.
     norm_w: fuse Qwen2RMSNorm(x)*norm_w into the GEMM prologue (M <= 16, K <= 4096).
     act8 (W8A8 mode, needs lin.w8m): the activations are rounded per row through e4m3 - on the fp8 matrix instruction for
     M > 64 rows, as a bf16 copy of the rounded rows for the weight-streaming kernels below that.
-    argmax_partial (int64 [M, ceil(N/16)], M <= 64): greedy-argmax keys per 16-column tile, finished by decode_step_end_argmax."""
+    argmax_partial (int64 [M, ceil(N/16)], M <= 64): greedy-argmax keys per 16-column tile, finished by decode_step_end_argmax.
+    sample (with argmax_partial): (temperature, seed, step tensor or None) - the keys then order bf16(logit / T) + Gumbel noise, so the
+    row maximum is one draw from softmax(logits / T) (bagel.py:1297-1299) instead of the greedy token."""
     lib = _lib.load()
     _req(x, BF16, "x")
     assert x.stride(-1) == 1
@@ -231,7 +233,7 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
             out=out.data_ptr(), ldo=out.stride(0),
             row_idx=row_idx.data_ptr() if row_idx is not None else None,
             M=M, N=lin.N, K=lin.K, epilogue=flags, norm_w=None, norm_eps=norm_eps, tile_rows=0,
-            w_scale=lin.scale.data_ptr(), argmax_partial=amax)
+            w_scale=lin.scale.data_ptr(), argmax_partial=amax, **_sample_fields(sample, amax))
         check(lib.umv_gemm_fp8w(C.byref(a), _stream()), "umv_gemm_fp8w")
         return out
     a = GemmArgs(
@@ -243,7 +245,7 @@ def gemm(x, lin, out=None, *, M=None, residual=None, act=None, row_idx=None, out
         row_idx=row_idx.data_ptr() if row_idx is not None else None,
         M=M, N=lin.N, K=lin.K, epilogue=flags,
         norm_w=norm_w.data_ptr() if norm_w is not None else None, norm_eps=norm_eps, tile_rows=lin.th, argmax_partial=amax,
-        x_rows=x.shape[0])
+        x_rows=x.shape[0], **_sample_fields(sample, amax))
     check(lib.umv_gemm_bf16(C.byref(a), _stream()), "umv_gemm_bf16")
     return out
 
@@ -380,6 +382,17 @@ def fake_quantize_act(x, M=None, row_idx=None):
     check(lib.umv_quantize_act_fp8(_p(x), x.stride(0), _p(row_idx), None, ldq, _p(xs), _p(out), out.stride(0), M, x.shape[1], _stream()),
           "umv_quantize_act_fp8")
     return out
+
+
+def _sample_fields(sample, amax):
+    if sample is None:
+        return {}
+    if amax is None:
+        raise _lib.UmvError("gemm: sample=(temperature, seed, step) is a mode of the argmax_partial epilogue")
+    t, seed, step = sample
+    if not float(t) > 0.0:
+        raise _lib.UmvError(f"gemm: sampling temperature must be > 0 (got {t})")
+    return dict(sample_temperature=float(t), sample_seed=int(seed) & (2 ** 64 - 1), sample_step=None if step is None else step.data_ptr())
 
 
 def gemm_splitk(x, lin, partials, k_splits, *, M=None):
