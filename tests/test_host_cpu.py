@@ -312,3 +312,33 @@ def test_w4_kernels_own_their_agprs(tmp_path):
         assert all(p > last_mfma for p in spills), f"{n}: the compiler spills into AGPRs while the k loop runs"
         assert tm <= 4 or not spills, f"{n}: {len(spills)} compiler spills into AGPRs while accumulators of a later epilogue chunk live there"
         assert scratch == 0 and "v_accvgpr_mov" not in body, f"{n}: scratch {scratch}"
+
+
+def test_attention_prefill_isa_has_no_scratch(tmp_path):
+    """The prefill attention kernels wait for their LDS-DMA pieces with hand-counted `s_waitcnt vmcnt(N)`; scratch traffic counts in vmcnt
+    too, so a build that spills registers inside the key loop gives WRONG results (round 5: the lazy-softmax hd 72 kernel held to 128 VGPRs
+    in a two-tiles-per-call form spilled 7 registers and failed on the GPU).  Compile the file to ISA (no GPU needed) and check every
+    kernel: no scratch, no compiler use of AGPRs as spill space, and the occupancy the launch policy counts on (hd 72 / TQ = 2: 4 waves
+    per SIMD, hd 128 / TQ = 2: 3)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "unimedvl_amd", "csrc", "attention_prefill.hip")
+    out = str(tmp_path / "ap.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                        "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = open(out).read()
+    names = re.findall(r"^(_Z19attn_prefill_kernelILi(\d+)ELi(\d+)ELb(\d)EEv\w+):", s, re.M)
+    assert len(names) == 8, names          # hd 128 / 72 x TQ 1 / 2 x lazy / exact
+    for n, hd, tq, lazy in names:
+        b = s.index(".Lfunc_end", s.index(n + ":"))
+        scratch = int(re.compile(r"; ScratchSize: (\d+)").search(s, b).group(1))
+        occ = int(re.compile(r"; Occupancy: (\d+)").search(s, b).group(1))
+        agprs = int(re.compile(r"; NumAgprs: (\d+)").search(s, b).group(1))
+        assert scratch == 0 and agprs == 0, f"{n}: scratch {scratch}, AGPRs {agprs}"
+        if tq == "2":
+            assert occ >= (4 if hd == "72" else 3), f"{n}: occupancy {occ}"

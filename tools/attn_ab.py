@@ -34,7 +34,31 @@ def run(nseg, Lq, Lk, nq, nkv, hd, causal, reps=5):
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 4.0 * nseg * nq * Lq * Lk * hd * (0.5 if causal and Lq == Lk else 1.0)
     h = hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:16]
-    print(f"nseg={nseg} Lq={Lq} Lk={Lk} nq={nq} nkv={nkv} hd={hd} causal={int(causal)}  {us:9.1f} us {flops / us / 1e6:7.1f} TF/s  sha {h}")
+    acc = ""
+    if os.environ.get("ATTN_AB_REF", "0") != "0" and nseg * Lq * Lk * nq <= 8 * 1026 * 1026 * 28:      # error against exact fp32 attention
+        G = nq // nkv
+        worst, mean = 0.0, 0.0
+        for sg in range(nseg):
+            qs = q[sg * Lq:(sg + 1) * Lq].float()
+            k = slab.k[sg, :, :Lk].float().repeat_interleave(G, 0)
+            v = slab.vt[sg, :, :, :Lk].float().transpose(-1, -2).repeat_interleave(G, 0)
+            sc = torch.einsum("qhd,hkd->hqk", qs, k) / hd ** 0.5
+            if causal:
+                qi = torch.arange(Lq, device="cuda")[:, None]
+                ki = torch.arange(Lk, device="cuda")[None, :]
+                sc = sc.masked_fill(ki > Lk - Lq + qi, float("-inf"))
+            ref = torch.einsum("hqk,hkd->qhd", sc.softmax(-1), v)
+            d = (out[sg * Lq:(sg + 1) * Lq].float() - ref).abs()
+            worst, mean = max(worst, d.max().item()), mean + d.mean().item() / nseg
+        acc = f"  vs fp32: max {worst:.5f} mean {mean:.6f}"
+    if os.environ.get("ATTN_AB_SAVE"):
+        os.makedirs(os.environ["ATTN_AB_SAVE"], exist_ok=True)
+        torch.save(out.cpu(), os.path.join(os.environ["ATTN_AB_SAVE"], f"{nseg}_{Lq}_{Lk}_{nq}_{hd}_{int(causal)}.pt"))
+    if os.environ.get("ATTN_AB_CMP"):
+        o0 = torch.load(os.path.join(os.environ["ATTN_AB_CMP"], f"{nseg}_{Lq}_{Lk}_{nq}_{hd}_{int(causal)}.pt")).float()
+        d = (out.cpu().float() - o0).abs()
+        acc += f"  vs saved: max {d.max().item():.5f} equal {float((d == 0).float().mean()) * 100:.2f} %"
+    print(f"nseg={nseg} Lq={Lq} Lk={Lk} nq={nq} nkv={nkv} hd={hd} causal={int(causal)}  {us:9.1f} us {flops / us / 1e6:7.1f} TF/s  sha {h}{acc}")
 
 
 for args in [(8, 1024, 1024, 16, 16, 72, False), (8, 1026, 1026, 28, 4, 128, False), (8, 34, 1060, 28, 4, 128, True),

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#define ATTN_LAZY_TAU 8.0f       // lazy softmax reference: exponents stay <= ATTN_LAZY_TAU (P <= 256)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for_attn(F&& f) {
@@ -36,6 +37,8 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 // keeps two blocks per stage (32-key stages cost it 47 -> 126 us per layer).  Same block order either way: bit-identical.
 constexpr int ATTN_PREFILL_NB(int hd, int tq) { return (tq == 2) ? 1 : 2; }
 constexpr int ATTN_PREFILL_WAVES(int hd, int tq) { return (hd <= 96 && tq == 2) ? 4 : 1; }   // minimum waves per SIMD asked of the register allocator
+// (a build that spills here is WRONG, not just slow: scratch traffic counts in vmcnt and the loop's waits are counted by hand.
+// tests/test_host_cpu.py::test_attention_prefill_isa_has_no_scratch compiles this file and checks every kernel.)
 
 __device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // keep the first nvalid (0..8) elements
     bf16x8 o;
@@ -44,7 +47,92 @@ __device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // ke
     return o;
 }
 
-template <int HD, int TQ>
+
+// Online softmax of one 32-key block against a LAZY reference point, for the TQ q-tiles of a wave at once (round 5).
+// P = 2^(s c - m_ref) with m_ref <= the row's running maximum <= m_ref + ATTN_LAZY_TAU: the reference moves (and O, l are rescaled by
+// alpha) only when some exponent exceeds ATTN_LAZY_TAU = 8 (P <= 256; the softmax is shift invariant, so only the rounding of P changes:
+// mean error against exact fp32 attention 9.2e-5 vs 8.7e-5 with the exact running maximum).  With the exact maximum the rescale fires
+// in most blocks - the maximum of n keys still moves with probability 32 / n per block and row, and a wave has 16 TQ rows.  The
+// trigger test runs on each lane's own eight exponents: no cross-lane step, no alpha, no 16 DT multiplies in the common path; the
+// row sums stay per-lane partials (reduced once, at the end).  State per row: nm = -m_ref (0 while unset), thr = ATTN_LAZY_TAU (-inf while
+// unset: any finite score of a row's first block sets the reference), l.  When the reference moves by d, the exponents already
+// computed are shifted (e - d) instead of recomputed from the scores: one rounding of ~1e-6 in the exponent, and the scores need
+// not stay live.  Returns true (wave-uniform) when the reference moved; alpha is written only then.
+template <int TQ, bool MASKED>
+__device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int kb, int g, const int (&limit)[TQ], const int (&my_end)[TQ], float c,
+                                                  float (&nm_run)[TQ], float (&thr_run)[TQ], float (&l_run)[TQ], float (&alpha)[TQ], bf16x8 (&pf)[TQ]) {
+    const umv_f32x2_v c2 = {c, c};
+    umv_f32x2_v e[TQ][4];
+    float emax[TQ];
+    bool trig = false;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[t * 4 + r] = st[u][t][r];
+                if constexpr (MASKED) {
+                    const int key = kb + g * 8 + t * 4 + r;
+                    v[t * 4 + r] = (key <= limit[u] && key < my_end[u]) ? v[t * 4 + r] : -INFINITY;
+                }
+            }
+        const umv_f32x2_v n2 = {nm_run[u], nm_run[u]};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) e[u][q4] = __builtin_elementwise_fma((umv_f32x2_v){v[2 * q4], v[2 * q4 + 1]}, c2, n2);   // (-inf) c + n = -inf
+        const float ea = umv_max3(e[u][0][0], e[u][0][1], e[u][1][0]), eb = umv_max3(e[u][1][1], e[u][2][0], e[u][2][1]);
+        emax[u] = umv_max3(ea, eb, umv_max2(e[u][3][0], e[u][3][1]));
+        trig = trig || emax[u] > thr_run[u];
+    }
+    const bool moved = __any(trig);
+    if (moved) {
+        // the rows' cross-lane maxima first, then the selects, branch-free
+        float mxr[TQ];
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            float mx = emax[u];
+            const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = umv_max2(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+            const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mxr[u] = umv_max2(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            const float mx = mxr[u];
+            const bool unset = thr_run[u] == -INFINITY;
+            const float mx0 = umv_max2(mx, 0.f);
+            float d = unset ? mx : mx0;                       // the reference rises by d (an unset row: to its first maximum)
+            d = (mx == -INFINITY) ? 0.f : d;
+            const float a2 = umv_exp2(-d);
+            alpha[u] = unset ? 1.0f : a2;                    // (an unset row has O = 0, l = 0)
+            l_run[u] *= alpha[u];
+            nm_run[u] -= d;
+            thr_run[u] = (mx == -INFINITY && unset) ? -INFINITY : ATTN_LAZY_TAU;
+            const umv_f32x2_v d2 = {d, d};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) e[u][q4] = e[u][q4] - d2;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        umv_f32x2_v pv[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) pv[q4] = (umv_f32x2_v){umv_exp2(e[u][q4][0]), umv_exp2(e[u][q4][1])};
+        const umv_f32x2_v s2 = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+        l_run[u] += s2[0] + s2[1];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const uint32_t w = pack2bf(pv[q4][0], pv[q4][1]);
+            pf[u][2 * q4] = (short)(w & 0xFFFFu);
+            pf[u][2 * q4 + 1] = (short)(w >> 16);
+        }
+    }
+    return moved;
+}
+
+template <int HD, int TQ, bool LAZY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e) {
     constexpr int KS = (HD + 31) / 32;
     constexpr int DT = (HD + 15) / 16;
@@ -144,10 +232,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
 
     f32x4 o[TQ][DT];
     float m_run[TQ], l_run[TQ];
+    float nm_run[TQ], thr_run[TQ];    // LAZY: -reference (0 while unset), trigger level (-inf while unset)
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         m_run[u] = -INFINITY;
         l_run[u] = 0.f;
+        nm_run[u] = 0.f;
+        thr_run[u] = -INFINITY;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -212,6 +303,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
             bool all_interior = true;
 #pragma unroll
             for (int u = 0; u < TQ; ++u) all_interior = all_interior && (kb + 32 <= my_end[u] && kb + 31 <= min_limit[u]);   // wave uniform
+            if constexpr (LAZY) {
+                // one call per q-tile (no attn_mfma_guard: the first consumer of the scores is a compiler-visible fma).  CAUTION: the two tiles
+                // of a wave in ONE call (attn_softmax_lazy<2, ..>: one trigger test, one rare path for both) compiled to a kernel that gave
+                // wrong rows in the SECOND tile now and then - never the same rows twice, whatever the trigger level, no scratch, and not
+                // cured by reordering the cross-lane steps around the EXEC writes or by wait states (tools/attn_lazy_det.py; cause not
+                // found).  Per tile, as the exact softmax is called, the kernel is deterministic (tests/test_kernel_branches_gpu.py::
+                // test_attn_lazy_softmax) and equal to the TQ = 1 kernel bit for bit.
+                static_for_attn<0, TQ>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    float a1[1] = {1.0f};
+                    const bool mv = all_interior
+                        ? attn_softmax_lazy<1, false>(reinterpret_cast<const f32x4 (&)[1][2]>(st[u]), kb, g, reinterpret_cast<const int (&)[1]>(limit[u]),
+                                                      reinterpret_cast<const int (&)[1]>(my_end[u]), scale_log2e, reinterpret_cast<float (&)[1]>(nm_run[u]),
+                                                      reinterpret_cast<float (&)[1]>(thr_run[u]), reinterpret_cast<float (&)[1]>(l_run[u]), a1,
+                                                      reinterpret_cast<bf16x8 (&)[1]>(pf[u]))
+                        : attn_softmax_lazy<1, true>(reinterpret_cast<const f32x4 (&)[1][2]>(st[u]), kb, g, reinterpret_cast<const int (&)[1]>(limit[u]),
+                                                     reinterpret_cast<const int (&)[1]>(my_end[u]), scale_log2e, reinterpret_cast<float (&)[1]>(nm_run[u]),
+                                                     reinterpret_cast<float (&)[1]>(thr_run[u]), reinterpret_cast<float (&)[1]>(l_run[u]), a1,
+                                                     reinterpret_cast<bf16x8 (&)[1]>(pf[u]));
+                    alpha[u] = mv ? a1[0] : 1.0f;
+                    rescale = rescale || mv;
+                });
+            } else {
             if (all_interior) {
                 if constexpr (TQ == 2) attn_mfma_guard(st[0][0], st[0][1], st[1][0], st[1][1]);      // raw accumulators go to asm maxima (common.h)
                 else attn_mfma_guard(st[0][0], st[0][1]);
@@ -220,6 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
             else static_for_attn<0, TQ>([&](auto U) { softmax_tile(U, std::true_type{}); });
 #pragma unroll
             for (int u = 0; u < TQ; ++u) rescale = rescale || __any(alpha[u] != 1.0f);
+            }
             // ---- O^T += V^T P^T : one V^T fragment from LDS feeds the TQ tiles
             // Straight-line code: the rescale and the tail mask are hoisted out of the dt loop as wave-uniform branches, so the
             // fragment reads are in flight before the first MFMA (with the branches inside the loop every fragment was a
@@ -272,6 +387,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
         }
 #endif
     }
+    // LAZY: the row sums were kept as per-lane partials; reduced here, in front of the first divergent store
+    if constexpr (LAZY) {
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) l_run[u] = xor32_sum(xor16_sum(l_run[u]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         if (!rvalid[u]) continue;
@@ -298,15 +419,15 @@ bool umv_attn_prefill_enabled() {
     return share != 0;
 }
 
-template <int HD, int TQ>
+template <int HD, int TQ, bool LAZY>
 static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
     constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
     constexpr int lds = 2 * ATTN_PREFILL_NB(HD, TQ) * (2 * KS + DT) * 1024;
     static bool attr[UMV_MAX_DEVICES] = {};
     if (umv_first_on_device(attr))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ, LAZY>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     dim3 grid((qtiles + 4 * TQ - 1) / (4 * TQ), a.nkv, a.nseg);
-    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ>), grid, dim3(256), lds, s, a, scale_log2e);
+    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY>), grid, dim3(256), lds, s, a, scale_log2e);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -332,6 +453,12 @@ extern "C" int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q)
 
 int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
     const bool two = prefill_two_qtiles(qtiles, a.nkv, a.nseg);
-    if (a.hd == 128) return two ? launch_prefill<128, 2>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1>(a, qtiles, scale_log2e, s);
-    return two ? launch_prefill<72, 2>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1>(a, qtiles, scale_log2e, s);
+    static int lazy = -1;
+    if (lazy < 0) { const char* e = getenv("UMV_ATTN_LAZY"); lazy = e ? atoi(e) : 1; }      // UMV_ATTN_LAZY=0: the exact-running-maximum softmax (A/B only)
+    if (lazy) {
+        if (a.hd == 128) return two ? launch_prefill<128, 2, true>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1, true>(a, qtiles, scale_log2e, s);
+        return two ? launch_prefill<72, 2, true>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1, true>(a, qtiles, scale_log2e, s);
+    }
+    if (a.hd == 128) return two ? launch_prefill<128, 2, false>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1, false>(a, qtiles, scale_log2e, s);
+    return two ? launch_prefill<72, 2, false>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1, false>(a, qtiles, scale_log2e, s);
 }
