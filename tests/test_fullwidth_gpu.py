@@ -244,8 +244,14 @@ def test_configs2_t2i_256_guided_flow_and_pixels(fw):
             d = (x[b * n_tok:(b + 1) * n_tok].cpu() - ox).abs()
             worst = max(worst, d.max().item())
             lat_devs.append(d.flatten())
-            # measured (MI355X, round 3): max 0.0625, mean 0.0056, p99 0.030 -> bounds at 2x
-            assert d.max().item() <= 0.125 and d.mean().item() < 0.012, f"sample {b} step {i}: latent max {d.max().item()} mean {d.mean().item()}"
+            # measured (MI355X): round 3, exact-running-maximum attention kernels (still there: UMV_ATTN_LAZY=0): max 0.0625, mean 0.0056,
+            # p99 0.030; round 5, lazy softmax reference (shipped): max 0.0625, mean up to 0.0121 at the last step.  The oracle's flash model
+            # rounds P = exp(s - max over ALL keys) to bf16 in one pass; a blockwise kernel rounds P against the reference point it has at
+            # that block - the running maximum (exact kernels: the final one once it has settled, hence the closer match) or the lazy
+            # reference (within 2^8 of it).  Both are equally far from exact fp32 attention (tests/test_kernel_branches_gpu.py::
+            # test_attn_lazy_softmax: mean 9.2e-5 vs 8.7e-5); the reference's own flash-attn kernel is blockwise too (64 / 128-key blocks).
+            # Bounds: max at 2x, mean at ~1.6x the lazy measurement (= 3.5x the exact one)
+            assert d.max().item() <= 0.125 and d.mean().item() < 0.02, f"sample {b} step {i}: latent max {d.max().item()} mean {d.mean().item()}"
         if b < 2:       # full-size VAE decoder + truncating uint8 (inferencer.py:234-256) on the ORACLE's latent for both
             px = vae.decode_tokens_to_uint8(olat[0], (hw, hw), model.latent_downsample, model.latent_patch_size).cpu()
             ref = oracle.decode_image(olat[0], (hw, hw))
@@ -264,7 +270,7 @@ def test_configs2_t2i_256_guided_flow_and_pixels(fw):
     allv = torch.cat(lat_devs)
     q = torch.quantile(allv[torch.randperm(allv.numel())[:2_000_000]].float(), torch.tensor([0.5, 0.9, 0.99, 0.999]))
     print(f"configs[2] B=4 256x256: latent deviation over {steps - 1} Euler steps: max {worst:.4f} (bound 0.125), mean {allv.mean().item():.5f} "
-          f"(bound 0.012), p50 / p90 / p99 / p99.9 = {q[0]:.4f} / {q[1]:.4f} / {q[2]:.4f} / {q[3]:.4f}")
+          f"(bound 0.02 per step), p50 / p90 / p99 / p99.9 = {q[0]:.4f} / {q[1]:.4f} / {q[2]:.4f} / {q[3]:.4f}")
 
 
 def _t2i_args(gl, gt, gim):
