@@ -622,7 +622,7 @@ def _attn_ab(env):
 def test_attn_kernel_variants_bit_identical():
     """tools/attn_ab.py as a test.  The exact-running-maximum family - the per-wave streaming kernel (UMV_ATTN_SHARED=0) and the LDS-shared
     kernels built with UMV_ATTN_LAZY=0, one q-tile per wave (UMV_ATTN_TQ=1) or two (UMV_ATTN_TQ=2) - produces the same bits on every shape
-    of the script; so do the two shipped lazy-reference kernels (TQ = 1, TQ = 2) among themselves."""
+    of the script; so do the two shipped lazy-reference kernels (TQ = 1, TQ = 2) among themselves, under either packing of the q-tiles."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a GPU")
     sha = lambda lines: [ln.split("sha")[-1].split()[0] for ln in lines]
@@ -631,6 +631,10 @@ def test_attn_kernel_variants_bit_identical():
     lazy1, lazy2 = sha(_attn_ab({"UMV_ATTN_TQ": "1"})), sha(_attn_ab({"UMV_ATTN_TQ": "2"}))
     assert lazy1 == lazy2, (lazy1, lazy2)
     assert lazy1 != wave          # (the lazy reference rounds P at another scale: same softmax, other bits)
+    # the packing of the (token, head) pairs into q-tiles (dense: 16 per tile at G = 7; UMV_ATTN_DENSE=0: whole tokens, 14) changes no bit:
+    # a row's keys, blocks and softmax reference are its own
+    assert sha(_attn_ab({"UMV_ATTN_DENSE": "0"})) == lazy1
+    assert sha(_attn_ab({"UMV_ATTN_DENSE": "0", "UMV_ATTN_LAZY": "0"})) == wave
 
 
 def test_attn_lazy_softmax():

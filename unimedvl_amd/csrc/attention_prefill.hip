@@ -102,14 +102,15 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
         for (int u = 0; u < TQ; ++u) {
             const float mx = mxr[u];
             const bool unset = thr_run[u] == -INFINITY;
-            const float mx0 = umv_max2(mx, 0.f);
-            float d = unset ? mx : mx0;                       // the reference rises by d (an unset row: to its first maximum)
-            d = (mx == -INFINITY) ? 0.f : d;
+            // only the rows that crossed their OWN trigger level move (all lanes of a row agree after the cross-lane maximum): a row's
+            // result does not depend on which other rows share its tile - the tile packing below may change without changing a bit
+            const bool need = mx > thr_run[u];
+            const float d = need ? mx : 0.f;                 // the reference rises by d (an unset row: to its first maximum)
             const float a2 = umv_exp2(-d);
-            alpha[u] = unset ? 1.0f : a2;                    // (an unset row has O = 0, l = 0)
+            alpha[u] = (need && !unset) ? a2 : 1.0f;         // (an unset row has O = 0, l = 0)
             l_run[u] *= alpha[u];
             nm_run[u] -= d;
-            thr_run[u] = (mx == -INFINITY && unset) ? -INFINITY : ATTN_LAZY_TAU;
+            thr_run[u] = need ? ATTN_LAZY_TAU : thr_run[u];
             const umv_f32x2_v d2 = {d, d};
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) e[u][q4] = e[u][q4] - d2;
@@ -133,7 +134,7 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
 }
 
 template <int HD, int TQ, bool LAZY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e, int dense) {
     constexpr int KS = (HD + 31) / 32;
     constexpr int DT = (HD + 15) / 16;
     constexpr int FK = 2 * KS, FB = FK + DT;   // fragments (1 KiB each) per 32-key block: K then V^T
@@ -145,33 +146,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
     const int j = lane & 15, g = lane >> 4;
     const int G = a.nq / a.nkv;
     const int QPT = 16 / G > 0 ? 16 / G : 1;
+    // the 16 columns of a q-tile are (token, head) pairs of one kv head.  QPT packing: whole tokens, 16 / G of them (G = 7: 14 columns
+    // used); DENSE packing (round 5): pairs run on across tile boundaries, PPT = 16 per tile - 12.5 % fewer tiles at G = 7.  Per row
+    // nothing changes (same keys, same blocks, its own softmax reference): the two packings give the same bits.
+    const int PPT = dense ? 16 : G * QPT;
     const int s = blockIdx.z;
     const int kh = blockIdx.y;
     const int qt_wg = blockIdx.x * 4 * TQ;      // first q-tile of the workgroup
     const int q0 = a.cu_q[s];
     const int Lq = a.cu_q[s + 1] - q0;
     const int Lk = a.kv_len[s];
-    if (qt_wg * QPT >= Lq || Lk <= 0) return;   // uniform over the workgroup
+    const int npairs = Lq * G;
+    if (qt_wg * PPT >= npairs || Lk <= 0) return;   // uniform over the workgroup
 
-    const int ql = j / G, hg = j % G;
-    const int head = kh * G + hg;
-    int qi[TQ], limit[TQ], my_end[TQ], min_limit[TQ];
+    int qi[TQ], head[TQ], limit[TQ], my_end[TQ], min_limit[TQ];
     bool rvalid[TQ];
     bf16x8 qf[TQ][KS];
     int wave_end = 0;
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         const int qt = qt_wg + wave * TQ + u;
-        const bool active = qt * QPT < Lq;
-        qi[u] = qt * QPT + ql;
-        rvalid[u] = active && (j < G * QPT) && (qi[u] < Lq);
+        const int p0 = qt * PPT;                   // first (token, head) pair of the tile
+        const bool active = p0 < npairs;
+        const int pr = p0 + j;
+        qi[u] = pr / G;
+        head[u] = kh * G + (pr - qi[u] * G);
+        rvalid[u] = active && (j < PPT) && (pr < npairs);
+        const int first_tok = p0 / G, last_tok = min(Lq - 1, (p0 + PPT - 1) / G);
         limit[u] = a.causal ? (Lk - Lq + qi[u]) : (Lk - 1);     // bottom-right aligned causal mask
-        min_limit[u] = a.causal ? (Lk - Lq + qt * QPT) : (Lk - 1);
+        min_limit[u] = a.causal ? (Lk - Lq + first_tok) : (Lk - 1);
         int e = Lk;
-        if (a.causal) e = min(Lk, Lk - Lq + min(Lq - 1, qt * QPT + QPT - 1) + 1);
+        if (a.causal) e = min(Lk, Lk - Lq + last_tok + 1);
         my_end[u] = active ? e : 0;
         wave_end = max(wave_end, my_end[u]);
-        const bf16_t* qp = a.q + (int64_t)(q0 + (rvalid[u] ? qi[u] : 0)) * (a.q_row_stride ? a.q_row_stride : (int64_t)a.nq * HD) + head * HD;
+        const bf16_t* qp = a.q + (int64_t)(q0 + (rvalid[u] ? qi[u] : 0)) * (a.q_row_stride ? a.q_row_stride : (int64_t)a.nq * HD) + (rvalid[u] ? head[u] : 0) * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 32 + g * 8;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
     }
     int blk_end = Lk;
     if (a.causal) {
-        const int last_blk = min(Lq - 1, (qt_wg + 4 * TQ - 1) * QPT + QPT - 1);
+        const int last_blk = min(Lq - 1, ((qt_wg + 4 * TQ - 1) * PPT + PPT - 1) / G);
         blk_end = min(Lk, Lk - Lq + last_blk + 1);
     }
     const int nstages = (blk_end + 32 * NB - 1) / (32 * NB);
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
     for (int u = 0; u < TQ; ++u) {
         if (!rvalid[u]) continue;
         const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
-        bf16_t* op = a.out + ((int64_t)(q0 + qi[u]) * a.nq + head) * HD;
+        bf16_t* op = a.out + ((int64_t)(q0 + qi[u]) * a.nq + head[u]) * HD;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + g * 4;
@@ -420,14 +428,14 @@ bool umv_attn_prefill_enabled() {
 }
 
 template <int HD, int TQ, bool LAZY>
-static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
+static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, int dense, hipStream_t s) {
     constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
     constexpr int lds = 2 * ATTN_PREFILL_NB(HD, TQ) * (2 * KS + DT) * 1024;
     static bool attr[UMV_MAX_DEVICES] = {};
     if (umv_first_on_device(attr))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ, LAZY>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     dim3 grid((qtiles + 4 * TQ - 1) / (4 * TQ), a.nkv, a.nseg);
-    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY>), grid, dim3(256), lds, s, a, scale_log2e);
+    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY>), grid, dim3(256), lds, s, a, scale_log2e, dense);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -437,7 +445,19 @@ static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e,
 static bool prefill_two_qtiles(int qtiles, int nkv, int nseg) {
     static int tq = -1;
     if (tq < 0) { const char* e = getenv("UMV_ATTN_TQ"); tq = e ? atoi(e) : 0; }
-    return tq == 2 || (tq != 1 && (long)((qtiles + 7) / 8) * nkv * nseg >= 512);
+    return tq == 2 || (tq != 1 && (long)((qtiles + 7) / 8) * nkv * nseg >= 448);      // (448 = 512 x 14 / 16: the flow pass of B = 4 text-to-image, 480 workgroups of dense tiles, keeps TQ = 2: 29 vs 33 us)
+}
+
+// q-tiles of the LDS-shared kernels: dense packing of the (token, head) pairs when 16 is not a multiple of the group size (G = 7: 16
+// pairs per tile instead of 14); UMV_ATTN_DENSE=0 keeps whole tokens per tile (A/B only; same bits either way)
+static bool attn_dense(int G) {
+    static int dense = -1;
+    if (dense < 0) { const char* e = getenv("UMV_ATTN_DENSE"); dense = e ? atoi(e) : 1; }
+    return dense != 0 && (16 % G) != 0 && G < 16;
+}
+static int prefill_qtiles(int max_q, int G) {
+    const int QPT = 16 / G > 0 ? 16 / G : 1;
+    return attn_dense(G) ? (max_q * G + 15) / 16 : (max_q + QPT - 1) / QPT;
 }
 
 // Which prefill-attention kernel umv_attn_varlen sends a (nsplit = 1) call to: 0 = the per-wave streaming attn_kernel,
@@ -446,19 +466,21 @@ extern "C" int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q)
     if (nkv <= 0 || nq % nkv || nseg <= 0 || max_q <= 0) return 0;
     const int G = nq / nkv;
     const int QPT = 16 / G > 0 ? 16 / G : 1;
-    const int qtiles = (max_q + QPT - 1) / QPT;
-    if (!(qtiles >= 4 && (hd == 128 || hd == 72) && umv_attn_prefill_enabled())) return 0;
-    return prefill_two_qtiles(qtiles, nkv, nseg) ? 2 : 1;
+    if (!((max_q + QPT - 1) / QPT >= 4 && (hd == 128 || hd == 72) && umv_attn_prefill_enabled())) return 0;
+    return prefill_two_qtiles(prefill_qtiles(max_q, G), nkv, nseg) ? 2 : 1;
 }
 
-int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s) {
+int umv_attn_prefill_launch(const umv_attn_args& a, int /*qtiles of the per-wave kernel*/, float scale_log2e, hipStream_t s) {
+    const int G = a.nq / a.nkv;
+    const int dense = attn_dense(G) ? 1 : 0;
+    const int qtiles = prefill_qtiles(a.max_q, G);
     const bool two = prefill_two_qtiles(qtiles, a.nkv, a.nseg);
     static int lazy = -1;
     if (lazy < 0) { const char* e = getenv("UMV_ATTN_LAZY"); lazy = e ? atoi(e) : 1; }      // UMV_ATTN_LAZY=0: the exact-running-maximum softmax (A/B only)
     if (lazy) {
-        if (a.hd == 128) return two ? launch_prefill<128, 2, true>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1, true>(a, qtiles, scale_log2e, s);
-        return two ? launch_prefill<72, 2, true>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1, true>(a, qtiles, scale_log2e, s);
+        if (a.hd == 128) return two ? launch_prefill<128, 2, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, true>(a, qtiles, scale_log2e, dense, s);
+        return two ? launch_prefill<72, 2, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<72, 1, true>(a, qtiles, scale_log2e, dense, s);
     }
-    if (a.hd == 128) return two ? launch_prefill<128, 2, false>(a, qtiles, scale_log2e, s) : launch_prefill<128, 1, false>(a, qtiles, scale_log2e, s);
-    return two ? launch_prefill<72, 2, false>(a, qtiles, scale_log2e, s) : launch_prefill<72, 1, false>(a, qtiles, scale_log2e, s);
+    if (a.hd == 128) return two ? launch_prefill<128, 2, false>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, false>(a, qtiles, scale_log2e, dense, s);
+    return two ? launch_prefill<72, 2, false>(a, qtiles, scale_log2e, dense, s) : launch_prefill<72, 1, false>(a, qtiles, scale_log2e, dense, s);
 }
