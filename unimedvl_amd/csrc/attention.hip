@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
             }
         float alpha;
         bf16x8 pf;
-        attn_softmax_block(sc, scale_log2e, m_run, l_run, alpha, pf);      // (shared with attn_prefill_kernel: same bits)
+        attn_softmax_block(sc, scale_log2e, m_run, l_run, alpha, pf);      // (shared with the exact-maximum prefill kernels, UMV_ATTN_LAZY=0: same bits)
         // ---- O^T += V^T P^T ; A = V^T[d = dt*16 + (lane&15)][kb + g*8 .. +8]
         const bool partial = kb + 32 > Lk;
         const int nvalid = min(8, max(0, Lk - (kb + g * 8)));

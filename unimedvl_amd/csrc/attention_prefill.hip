@@ -9,10 +9,12 @@
 //     address, the destination is lane-linear, so the consumers' ds_read_b128 are conflict free), double buffered, one
 //     barrier per stage;
 //   * a fragment read from LDS feeds TQ MFMAs (one per q-tile of the wave): half the LDS bytes per flop at TQ = 2;
-//   * interior blocks skip the per-element causal / length masks, and the O rescale is skipped once the running maxima
-//     have settled (alpha == 1 in every lane) - both exact.
-// Per row the arithmetic and its order are those of attn_kernel (both call common.h::attn_softmax_block): results are bit-identical
-// (tools/attn_ab.py, tests/test_kernel_branches_gpu.py::test_attn_kernel_variants_bit_identical).
+//   * interior blocks skip the per-element causal / length masks;
+//   * round 5, the shipped form (LAZY): the softmax runs against a lazy reference point (attn_softmax_lazy below) and the q-tiles pack
+//     the (token, head) pairs densely (16 per tile at any group size).  Same softmax, P rounded at another scale than attn_kernel's.
+// With UMV_ATTN_LAZY=0 the kernels keep the exact running maximum: per row the arithmetic and its order are then those of attn_kernel
+// (both call common.h::attn_softmax_block) and the results are bit-identical to it; the lazy kernels (TQ = 1, 2, either packing) are
+// bit-identical among themselves (tools/attn_ab.py, tests/test_kernel_branches_gpu.py::test_attn_kernel_variants_bit_identical).
 #include "common.h"
 #include "../../include/unimedvl_hip.h"
 #include <stdlib.h>
