@@ -251,7 +251,23 @@ typedef struct {
      * column, k_head_stride is the head pitch inside a row, k_seg_stride is ignored (self-attention without a cache: the
      * SigLIP tower, siglip_navit.py:232-241).  V^T always comes from vt_slab. */
     int64_t q_row_stride, k_key_stride;
+    /* Optional, for tests and A/B runs (0 / NULL in production).  variant: 0 = the library's own shape -> kernel policy; with
+     * UMV_ATTN_VARIANT_FORCE set, the other UMV_ATTN_VARIANT_* bits pick the nsplit = 1 kernel for THIS call (a per-call value: the
+     * library keeps no mutable state).  stats: two device counters the lazy-softmax kernels add to - [0] the (wave, q-tile, 32-key block)
+     * events in which the softmax reference moved on a NON-EMPTY accumulator (O and l rescaled by alpha), [1] those in which a row's
+     * reference was set for the first time. */
+    int variant;
+    uint32_t* stats;
 } umv_attn_args;
+enum {
+    UMV_ATTN_VARIANT_FORCE = 1,        /* the bits below replace the process policy (and its UMV_ATTN_* environment knobs) */
+    UMV_ATTN_VARIANT_STREAM = 2,       /* the per-wave streaming kernel (attn_kernel) even where the LDS-shared kernels would run */
+    UMV_ATTN_VARIANT_TQ1 = 4,          /* LDS-shared kernel, one q-tile per wave */
+    UMV_ATTN_VARIANT_TQ2 = 8,          /* ... two q-tiles per wave (neither bit: by grid size) */
+    UMV_ATTN_VARIANT_EXACT = 16,       /* exact running maximum (the bits of attn_kernel) instead of the lazy softmax reference */
+    UMV_ATTN_VARIANT_WHOLE_TOKENS = 32,/* q-tiles of whole tokens instead of densely packed (token, head) pairs */
+    UMV_ATTN_VARIANT_PAIR = 64         /* lazy softmax with both q-tiles of a wave in one call (TQ2 only) */
+};
 size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit);
 int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);
 /* Host-only query: which kernel an nsplit = 1 call goes to: 0 = per-wave streaming kernel, 1 / 2 = the LDS-shared

@@ -68,6 +68,43 @@ def test_ctypes_structs_match_the_header(tmp_path):
             assert getattr(cls, n).offset == c[cs][n], f"{cs}.{n}: offset {c[cs][n]} in C, {getattr(cls, n).offset} in ctypes"
 
 
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_integration_md_stubs_match_the_header(tmp_path):
+    """INTEGRATION.md section 2 shows a maintainer the ctypes binding to paste into the reference tree.  Every `ctypes.Structure` block
+    in that file is EXECUTED here and compared with the layout gcc gives the header's struct it claims to mirror (size, field order,
+    every offset) and with unimedvl_amd._lib's own mirror: a stub that lags the header (a copied GemmArgs was 32 bytes
+    short, the library would have read garbage for the sampling fields) fails the CPU suite."""
+    from unimedvl_amd import _lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"^class (\w+)\(ctypes\.Structure\):\s*#\s*mirrors (umv_\w+)[^\n]*\n(\s+_fields_ = \[.*?\])\n", md, flags=re.S | re.M)
+    assert {b[0] for b in blocks} >= {"GemmArgs", "AttnArgs"}, [b[0] for b in blocks]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for _, cs, _ in blocks:
+        lines.append(f'  printf("{cs} size %zu\\n", sizeof({cs}));')
+        for f in _c_fields(cs):
+            lines.append(f'  printf("{cs} {f} %zu\\n", offsetof({cs}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi_md.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi_md"
+    subprocess.check_call(["gcc", "-std=c11", f"-I{INCLUDE}", "-o", str(exe), str(src)])
+    c = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        st, f, v = ln.split()
+        c.setdefault(st, {})[f] = int(v)
+    for pyname, cs, fields_src in blocks:
+        ns = {"ctypes": ctypes}
+        exec(f"class {pyname}(ctypes.Structure):\n{fields_src}\n", ns)
+        cls = ns[pyname]
+        names = [n for n, _ in cls._fields_]
+        assert names == _c_fields(cs), f"INTEGRATION.md {pyname}: fields differ from {cs}\n C : {_c_fields(cs)}\n md: {names}"
+        assert ctypes.sizeof(cls) == c[cs]["size"], f"INTEGRATION.md {pyname}: sizeof {ctypes.sizeof(cls)} vs {c[cs]['size']} in C"
+        for n in names:
+            assert getattr(cls, n).offset == c[cs][n], f"INTEGRATION.md {pyname}.{n}: offset {getattr(cls, n).offset} vs {c[cs][n]} in C"
+        mine = getattr(_lib, pyname)
+        assert [(n, ctypes.sizeof(t)) for n, t in cls._fields_] == [(n, ctypes.sizeof(t)) for n, t in mine._fields_]
+
+
 def test_ctypes_signatures_match_the_header():
     """Every function the header declares is bound in _lib._SIGS with the same number of parameters, pointer parameters as
     pointers / void*, 64-bit integers as 64-bit, floats as floats."""

@@ -481,3 +481,55 @@ def test_timestep_embed(ops):
     assert got.shape == ref.shape == (t.numel(), 256)
     assert_close_bf16(got, ref, max_ulp=1, frac_exact=0.999, what="timestep sinusoid")
     assert torch.equal(got[49].cpu(), ref[49])          # t = 0: cos = 1, sin = 0 exactly
+
+
+def _splitmix64(x):
+    import numpy as np
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def test_sampling_uniform_extremes_cannot_pick_a_token_by_themselves(ops):
+    """with u in (0, 1] the draw u == 1 (probability 2^-24 per column, ~1 % per draw over a 152 k vocabulary) gave +inf Gumbel
+    noise / a zero exponential: that column won WHATEVER its logit.  u is now (r + 0.5) 2^-23, r = the top 23 bits of the hash.  The test
+    searches the counter-based generator's stream (splitmix64 keyed by seed, step, row, column - restated here) for (seed, column) pairs
+    whose r is all ones (the draw nearest 1) resp. zero (nearest 0), gives that column a logit 30 below the rest (p ~ 1e-13 after the
+    softmax) and -inf, and checks that neither sampler picks it - umv_sample_bf16 and the lm_head epilogue draw from the same stream."""
+    import numpy as np
+    V, K = 4096, 32
+    cols = np.arange(V, dtype=np.uint64)
+    found = {}
+    with np.errstate(over="ignore"):
+        for seed in range(1, 20000):
+            row_key = _splitmix64(np.uint64(seed))            # step 0, row 0: seed ^ 0 ^ 0
+            r = _splitmix64(row_key + cols) >> np.uint64(41)
+            for want, name in ((0x7FFFFF, "top"), (0, "bottom")):
+                hit = np.nonzero(r == np.uint64(want))[0]
+                if len(hit) and name not in found:
+                    found[name] = (seed, int(hit[0]))
+            if len(found) == 2:
+                break
+    assert len(found) == 2, found
+    for name, (seed, col) in found.items():
+        for low in (-30.0, float("-inf")):
+            logits = torch.zeros((1, V))
+            logits[0, col] = low
+            lg = logits.to(BF16).cuda()
+            tok = int(ops.sample(lg, 1.0, seed=seed)[0])
+            assert tok != col, f"umv_sample_bf16 picked column {col} (logit {low}) on the '{name}' extreme of the uniform"
+            # the same through the lm_head epilogue: logits = W[:, 0] with x = e_0
+            w = torch.zeros((V, K))
+            w[:, 0] = logits[0].clamp_min(-3e38)
+            lin = ops.PackedLinear.from_weight(w.to(BF16).cuda())
+            x = torch.zeros((1, K), dtype=BF16, device="cuda")
+            x[0, 0] = 1.0
+            keys = torch.zeros((1, (V + 15) // 16), dtype=torch.int64, device="cuda")
+            out = torch.empty((1, V), dtype=BF16, device="cuda")
+            ops.gemm(x, lin, out=out, argmax_partial=keys, sample=(1.0, seed, None))
+            k = keys.cpu().numpy().view(np.uint64).max(axis=1)
+            tok2 = int(np.uint64(0xFFFFFFFF) - (k[0] & np.uint64(0xFFFFFFFF)))
+            assert tok2 != col, f"the lm_head epilogue picked column {col} (logit {low}) on the '{name}' extreme of the uniform"
+            if name == "top" and low == -30.0:
+                assert tok == tok2, "both samplers draw from one stream: same seed, same token"

@@ -46,7 +46,12 @@ class AttnArgs(C.Structure):
         ("nseg", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("causal", C.c_int),
         ("max_q", C.c_int), ("max_kv", C.c_int), ("nsplit", C.c_int), ("workspace", C.c_void_p),
         ("q_row_stride", C.c_int64), ("k_key_stride", C.c_int64),
+        ("variant", C.c_int), ("stats", C.c_void_p),
     ]
+
+
+# umv_attn_args.variant bits (tests / A-B only): FORCE makes the others replace the library's shape -> kernel policy for one call
+ATTN_FORCE, ATTN_STREAM, ATTN_TQ1, ATTN_TQ2, ATTN_EXACT, ATTN_WHOLE_TOKENS, ATTN_PAIR = 1, 2, 4, 8, 16, 32, 64
 
 
 class Gemm8Args(C.Structure):

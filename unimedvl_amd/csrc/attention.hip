@@ -16,7 +16,8 @@
 #include "../../include/unimedvl_hip.h"
 
 // attention_prefill.hip: the nsplit == 1 path with K / V^T shared through LDS (bit-identical results)
-bool umv_attn_prefill_enabled();
+bool umv_attn_prefill_enabled(int variant);
+bool umv_attn_prefill_can_take(const umv_attn_args& a);
 int umv_attn_prefill_launch(const umv_attn_args& a, int qtiles, float scale_log2e, hipStream_t s);
 
 __device__ __forceinline__ bf16x8 mask_keys(bf16x8 v, int nvalid) {
@@ -225,7 +226,7 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     dim3 grid((qtiles + wpb - 1) / wpb, a.nkv * a.nsplit, a.nseg), block(64 * wpb);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
-    if (a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72) && umv_attn_prefill_enabled())
+    if (a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72) && umv_attn_prefill_enabled(a.variant) && umv_attn_prefill_can_take(a))
         return umv_attn_prefill_launch(a, qtiles, scale_log2e, s);
     if (a.hd == 128)
         hipLaunchKernelGGL((attn_kernel<128>), grid, block, 0, s, a, scale_log2e);

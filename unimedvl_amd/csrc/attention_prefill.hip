@@ -60,9 +60,10 @@ __device__ __forceinline__ bf16x8 attn_mask_keys(bf16x8 v, int nvalid) {   // ke
 // unset: any finite score of a row's first block sets the reference), l.  When the reference moves by d, the exponents already
 // computed are shifted (e - d) instead of recomputed from the scores: one rounding of ~1e-6 in the exponent, and the scores need
 // not stay live.  Returns true (wave-uniform) when the reference moved; alpha is written only then.
-template <int TQ, bool MASKED>
+template <int TQ, bool MASKED, bool STATS>
 __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int kb, int g, const int (&limit)[TQ], const int (&my_end)[TQ], float c,
-                                                  float (&nm_run)[TQ], float (&thr_run)[TQ], float (&l_run)[TQ], float (&alpha)[TQ], bf16x8 (&pf)[TQ]) {
+                                                  float (&nm_run)[TQ], float (&thr_run)[TQ], float (&l_run)[TQ], float (&alpha)[TQ], bf16x8 (&pf)[TQ],
+                                                  uint32_t (&cnt)[2]) {
     const umv_f32x2_v c2 = {c, c};
     umv_f32x2_v e[TQ][4];
     float emax[TQ];
@@ -83,8 +84,12 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
         const umv_f32x2_v n2 = {nm_run[u], nm_run[u]};
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) e[u][q4] = __builtin_elementwise_fma((umv_f32x2_v){v[2 * q4], v[2 * q4 + 1]}, c2, n2);   // (-inf) c + n = -inf
-        const float ea = umv_max3(e[u][0][0], e[u][0][1], e[u][1][0]), eb = umv_max3(e[u][1][1], e[u][2][0], e[u][2][1]);
-        emax[u] = umv_max3(ea, eb, umv_max2(e[u][3][0], e[u][3][1]));
+        // Every instruction of this function is COMPILER-VISIBLE (round 6): the exponents are fma results, which the compiler knows to be
+        // canonical, so fmaxf folds into v_max3_f32 without the v_max_f32 x, x it needs on raw MFMA results (the reason common.h's
+        // attn_softmax_block takes its maxima as inline asm) - and the hazard recogniser sees every producer and consumer of the
+        // v_permlane*_swap steps below (VALU write -> swap read needs wait states that it cannot place around inline asm).
+        const float ea = fmaxf(fmaxf(e[u][0][0], e[u][0][1]), e[u][1][0]), eb = fmaxf(fmaxf(e[u][1][1], e[u][2][0]), e[u][2][1]);
+        emax[u] = fmaxf(fmaxf(ea, eb), fmaxf(e[u][3][0], e[u][3][1]));
         trig = trig || emax[u] > thr_run[u];
     }
     const bool moved = __any(trig);
@@ -92,13 +97,7 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
         // the rows' cross-lane maxima first, then the selects, branch-free
         float mxr[TQ];
 #pragma unroll
-        for (int u = 0; u < TQ; ++u) {
-            float mx = emax[u];
-            const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = umv_max2(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
-            const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mxr[u] = umv_max2(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
-        }
+        for (int u = 0; u < TQ; ++u) mxr[u] = xor32_max(xor16_max(emax[u]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < TQ; ++u) {
@@ -116,6 +115,12 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
             const umv_f32x2_v d2 = {d, d};
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) e[u][q4] = e[u][q4] - d2;
+            // diagnostics of the parity tests (umv_attn_args.stats, the STATS kernels only): how often each form of the rare path ran.
+            // Wave-uniform counters, added to memory once at the end of the kernel
+            if constexpr (STATS) {
+                cnt[0] += __any(need && !unset) ? 1u : 0u;
+                cnt[1] += __any(need && unset) ? 1u : 0u;
+            }
         }
     }
 #pragma unroll
@@ -135,8 +140,11 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
     return moved;
 }
 
-template <int HD, int TQ, bool LAZY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e, int dense) {
+// LAZY: 0 = exact running maximum, 1 = lazy reference (one softmax call per q-tile), 2 = lazy, both tiles in one call.  STATS: the kernel
+// also counts its rare-path events into umv_attn_args.stats (a separate instantiation, selected when stats != NULL: the counters cost the
+// hd-72 two-tile kernel the last of its 128 registers; same arithmetic, and the tests compare its output with the plain kernel's bit for bit)
+template <int HD, int TQ, int LAZY, bool STATS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STATS ? 1 : ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e, int dense) {
     constexpr int KS = (HD + 31) / 32;
     constexpr int DT = (HD + 15) / 16;
     constexpr int FK = 2 * KS, FB = FK + DT;   // fragments (1 KiB each) per 32-key block: K then V^T
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
     f32x4 o[TQ][DT];
     float m_run[TQ], l_run[TQ];
     float nm_run[TQ], thr_run[TQ];    // LAZY: -reference (0 while unset), trigger level (-inf while unset)
+    uint32_t cnt[2] = {0u, 0u};       // LAZY: rare-path events of this wave (uniform), see umv_attn_args.stats
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         m_run[u] = -INFINITY;
@@ -313,25 +322,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
             bool all_interior = true;
 #pragma unroll
             for (int u = 0; u < TQ; ++u) all_interior = all_interior && (kb + 32 <= my_end[u] && kb + 31 <= min_limit[u]);   // wave uniform
-            if constexpr (LAZY) {
-                // one call per q-tile (no attn_mfma_guard: the first consumer of the scores is a compiler-visible fma).  CAUTION: the two tiles
-                // of a wave in ONE call (attn_softmax_lazy<2, ..>: one trigger test, one rare path for both) compiled to a kernel that gave
-                // wrong rows in the SECOND tile now and then - never the same rows twice, whatever the trigger level, no scratch, and not
-                // cured by reordering the cross-lane steps around the EXEC writes or by wait states (tools/attn_lazy_det.py; cause not
-                // found).  Per tile, as the exact softmax is called, the kernel is deterministic (tests/test_kernel_branches_gpu.py::
-                // test_attn_lazy_softmax) and equal to the TQ = 1 kernel bit for bit.
+            if constexpr (LAZY == 2) {
+                // both q-tiles of the wave in ONE call (one trigger test, one rare path): UMV_ATTN_VARIANT_PAIR, see the note below
+                rescale = all_interior ? attn_softmax_lazy<TQ, false, STATS>(st, kb, g, limit, my_end, scale_log2e, nm_run, thr_run, l_run, alpha, pf, cnt)
+                                       : attn_softmax_lazy<TQ, true, STATS>(st, kb, g, limit, my_end, scale_log2e, nm_run, thr_run, l_run, alpha, pf, cnt);
+                if (!rescale) {
+#pragma unroll
+                    for (int u = 0; u < TQ; ++u) alpha[u] = 1.0f;
+                }
+            } else if constexpr (LAZY == 1) {
+                // one call per q-tile.  Round 5 note: the two tiles of a wave in ONE call compiled to a kernel that gave wrong rows in the
+                // SECOND tile now and then - never the same rows twice.  In that build the maxima around the v_permlane*_swap steps were
+                // inline asm, invisible to the hazard recogniser; since round 6 attn_softmax_lazy is compiler-visible throughout, the
+                // paired form is kept as LAZY == 2 and both are held to a determinism stress test
+                // (tests/test_attn_lazy_gpu.py::test_lazy_kernels_are_deterministic).
                 static_for_attn<0, TQ>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     float a1[1] = {1.0f};
                     const bool mv = all_interior
-                        ? attn_softmax_lazy<1, false>(reinterpret_cast<const f32x4 (&)[1][2]>(st[u]), kb, g, reinterpret_cast<const int (&)[1]>(limit[u]),
+                        ? attn_softmax_lazy<1, false, STATS>(reinterpret_cast<const f32x4 (&)[1][2]>(st[u]), kb, g, reinterpret_cast<const int (&)[1]>(limit[u]),
                                                       reinterpret_cast<const int (&)[1]>(my_end[u]), scale_log2e, reinterpret_cast<float (&)[1]>(nm_run[u]),
                                                       reinterpret_cast<float (&)[1]>(thr_run[u]), reinterpret_cast<float (&)[1]>(l_run[u]), a1,
-                                                      reinterpret_cast<bf16x8 (&)[1]>(pf[u]))
-                        : attn_softmax_lazy<1, true>(reinterpret_cast<const f32x4 (&)[1][2]>(st[u]), kb, g, reinterpret_cast<const int (&)[1]>(limit[u]),
+                                                      reinterpret_cast<bf16x8 (&)[1]>(pf[u]), cnt)
+                        : attn_softmax_lazy<1, true, STATS>(reinterpret_cast<const f32x4 (&)[1][2]>(st[u]), kb, g, reinterpret_cast<const int (&)[1]>(limit[u]),
                                                      reinterpret_cast<const int (&)[1]>(my_end[u]), scale_log2e, reinterpret_cast<float (&)[1]>(nm_run[u]),
                                                      reinterpret_cast<float (&)[1]>(thr_run[u]), reinterpret_cast<float (&)[1]>(l_run[u]), a1,
-                                                     reinterpret_cast<bf16x8 (&)[1]>(pf[u]));
+                                                     reinterpret_cast<bf16x8 (&)[1]>(pf[u]), cnt);
                     alpha[u] = mv ? a1[0] : 1.0f;
                     rescale = rescale || mv;
                 });
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
 #endif
     }
     // LAZY: the row sums were kept as per-lane partials; reduced here, in front of the first divergent store
-    if constexpr (LAZY) {
+    if constexpr (LAZY != 0) {
 #pragma unroll
         for (int u = 0; u < TQ; ++u) l_run[u] = xor32_sum(xor16_sum(l_run[u]));
         __builtin_amdgcn_sched_barrier(0);
@@ -419,70 +435,112 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_PREFIL
             }
         }
     }
+    if constexpr (STATS) {
+        if (a.stats && lane == 0) {
+            if (cnt[0]) atomicAdd(a.stats + 0, cnt[0]);
+            if (cnt[1]) atomicAdd(a.stats + 1, cnt[1]);
+        }
+    }
 }
 
 
-// UMV_ATTN_SHARED=0 falls back to the per-wave streaming kernel; UMV_ATTN_TQ=1|2 picks the q-tiles per wave (A/B only)
-bool umv_attn_prefill_enabled() {
-    static int share = -1;
-    if (share < 0) { const char* e = getenv("UMV_ATTN_SHARED"); share = (e && atoi(e) == 0) ? 0 : 1; }
-    return share != 0;
+// ---------------------------------------------------------------------------------------------------------------- host side
+// The process-wide policy is read from the environment ONCE (thread-safe initialisation of a function-local static, immutable
+// afterwards): UMV_ATTN_SHARED=0 = the per-wave streaming kernel everywhere, UMV_ATTN_TQ=1|2 pins the q-tiles per wave,
+// UMV_ATTN_DENSE=0 = whole-token tiles, UMV_ATTN_LAZY=0|1|2 = the softmax form.  A call can replace it for itself through
+// umv_attn_args.variant (UMV_ATTN_VARIANT_FORCE | ...: the parity tests drive every kernel variant in one process that way).
+struct AttnPolicy { int shared, tq, dense, lazy; };
+static const AttnPolicy& attn_env_policy() {
+    static const AttnPolicy p = [] {
+        AttnPolicy q;
+        const char* e = getenv("UMV_ATTN_SHARED"); q.shared = (e && atoi(e) == 0) ? 0 : 1;
+        e = getenv("UMV_ATTN_TQ"); q.tq = e ? atoi(e) : 0;
+        e = getenv("UMV_ATTN_DENSE"); q.dense = e ? atoi(e) : 1;
+        e = getenv("UMV_ATTN_LAZY"); q.lazy = e ? atoi(e) : 1;
+        if (q.lazy < 0 || q.lazy > 2) q.lazy = 1;
+        return q;
+    }();
+    return p;
 }
+static AttnPolicy attn_policy(int variant) {
+    if (!(variant & UMV_ATTN_VARIANT_FORCE)) return attn_env_policy();
+    AttnPolicy q;
+    q.shared = (variant & UMV_ATTN_VARIANT_STREAM) ? 0 : 1;
+    q.tq = (variant & UMV_ATTN_VARIANT_TQ1) ? 1 : (variant & UMV_ATTN_VARIANT_TQ2) ? 2 : 0;
+    q.dense = (variant & UMV_ATTN_VARIANT_WHOLE_TOKENS) ? 0 : 1;
+    q.lazy = (variant & UMV_ATTN_VARIANT_EXACT) ? 0 : (variant & UMV_ATTN_VARIANT_PAIR) ? 2 : 1;
+    return q;
+}
+bool umv_attn_prefill_enabled(int variant) { return attn_policy(variant).shared != 0; }
 
-template <int HD, int TQ, bool LAZY>
+template <int HD, int TQ, int LAZY, bool STATS = false>
 static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, int dense, hipStream_t s) {
     constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
     constexpr int lds = 2 * ATTN_PREFILL_NB(HD, TQ) * (2 * KS + DT) * 1024;
     static bool attr[UMV_MAX_DEVICES] = {};
     if (umv_first_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ, LAZY>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ, LAZY, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     dim3 grid((qtiles + 4 * TQ - 1) / (4 * TQ), a.nkv, a.nseg);
-    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY>), grid, dim3(256), lds, s, a, scale_log2e, dense);
+    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY, STATS>), grid, dim3(256), lds, s, a, scale_log2e, dense);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
 
 // two q-tiles per wave only when that still leaves >= 2 workgroups per CU (measured: LLM prefill 496 -> 413 us, flow pass
 // 96 -> 83, ViT 152 -> 144; but 34-token text prefill 52 -> 73 us with only 96 workgroups)
-static bool prefill_two_qtiles(int qtiles, int nkv, int nseg) {
-    static int tq = -1;
-    if (tq < 0) { const char* e = getenv("UMV_ATTN_TQ"); tq = e ? atoi(e) : 0; }
-    return tq == 2 || (tq != 1 && (long)((qtiles + 7) / 8) * nkv * nseg >= 448);      // (448 = 512 x 14 / 16: the flow pass of B = 4 text-to-image, 480 workgroups of dense tiles, keeps TQ = 2: 29 vs 33 us)
+static bool prefill_two_qtiles(const AttnPolicy& p, int qtiles, int nkv, int nseg) {
+    return p.tq == 2 || (p.tq != 1 && (long)((qtiles + 7) / 8) * nkv * nseg >= 448);      // (448 = 512 x 14 / 16: the flow pass of B = 4 text-to-image, 480 workgroups of dense tiles, keeps TQ = 2: 29 vs 33 us)
 }
 
 // q-tiles of the LDS-shared kernels: dense packing of the (token, head) pairs when 16 is not a multiple of the group size (G = 7: 16
 // pairs per tile instead of 14); UMV_ATTN_DENSE=0 keeps whole tokens per tile (A/B only; same bits either way)
-static bool attn_dense(int G) {
-    static int dense = -1;
-    if (dense < 0) { const char* e = getenv("UMV_ATTN_DENSE"); dense = e ? atoi(e) : 1; }
-    return dense != 0 && (16 % G) != 0 && G < 16;
-}
-static int prefill_qtiles(int max_q, int G) {
+static bool attn_dense(const AttnPolicy& p, int G) { return p.dense != 0 && (16 % G) != 0 && G < 16; }
+static int prefill_qtiles(const AttnPolicy& p, int max_q, int G) {
     const int QPT = 16 / G > 0 ? 16 / G : 1;
-    return attn_dense(G) ? (max_q * G + 15) / 16 : (max_q + QPT - 1) / QPT;
+    return attn_dense(p, G) ? (max_q * G + 15) / 16 : (max_q + QPT - 1) / QPT;
 }
 
-// Which prefill-attention kernel umv_attn_varlen sends a (nsplit = 1) call to: 0 = the per-wave streaming attn_kernel,
-// 1 / 2 = attn_prefill_kernel<hd, TQ>.  Exported so that tests can assert that a case reaches the TQ = 2 kernels.
+// Which prefill-attention kernel umv_attn_varlen sends a (nsplit = 1) call to under the process policy: 0 = the per-wave streaming
+// attn_kernel, 1 / 2 = attn_prefill_kernel<hd, TQ>.  Exported so that tests can assert that a case reaches the TQ = 2 kernels.
 extern "C" int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q) {
     if (nkv <= 0 || nq % nkv || nseg <= 0 || max_q <= 0) return 0;
+    const AttnPolicy& p = attn_env_policy();
     const int G = nq / nkv;
     const int QPT = 16 / G > 0 ? 16 / G : 1;
-    if (!((max_q + QPT - 1) / QPT >= 4 && (hd == 128 || hd == 72) && umv_attn_prefill_enabled())) return 0;
-    return prefill_two_qtiles(prefill_qtiles(max_q, G), nkv, nseg) ? 2 : 1;
+    if (!((max_q + QPT - 1) / QPT >= 4 && (hd == 128 || hd == 72) && p.shared)) return 0;
+    return prefill_two_qtiles(p, prefill_qtiles(p, max_q, G), nkv, nseg) ? 2 : 1;
+}
+
+// The LDS-shared kernels address K and V^T through buffer resources: 32-bit byte offsets and a range check that is clamped to
+// 2^31 - 1 bytes.  A (segment, kv head) whose K rows or V^T rows span more than that cannot be taken (keys beyond the clamp would read
+// as zeros, unmasked): umv_attn_varlen keeps such a call on the per-wave kernel, which uses 64-bit addresses.
+bool umv_attn_prefill_can_take(const umv_attn_args& a) {
+    const int64_t kstride = a.k_key_stride ? a.k_key_stride : a.hd;
+    const int64_t kbytes = ((int64_t)a.max_kv + 64) * kstride * 2;      // (+ the blocks a stage may run past the last key)
+    const int64_t vbytes = (int64_t)a.hd * a.v_d_stride * 2;
+    return kbytes < (int64_t)0x7FFFFFFF && vbytes < (int64_t)0x7FFFFFFF;
 }
 
 int umv_attn_prefill_launch(const umv_attn_args& a, int /*qtiles of the per-wave kernel*/, float scale_log2e, hipStream_t s) {
+    const AttnPolicy p = attn_policy(a.variant);
     const int G = a.nq / a.nkv;
-    const int dense = attn_dense(G) ? 1 : 0;
-    const int qtiles = prefill_qtiles(a.max_q, G);
-    const bool two = prefill_two_qtiles(qtiles, a.nkv, a.nseg);
-    static int lazy = -1;
-    if (lazy < 0) { const char* e = getenv("UMV_ATTN_LAZY"); lazy = e ? atoi(e) : 1; }      // UMV_ATTN_LAZY=0: the exact-running-maximum softmax (A/B only)
-    if (lazy) {
-        if (a.hd == 128) return two ? launch_prefill<128, 2, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, true>(a, qtiles, scale_log2e, dense, s);
-        return two ? launch_prefill<72, 2, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<72, 1, true>(a, qtiles, scale_log2e, dense, s);
+    const int dense = attn_dense(p, G) ? 1 : 0;
+    const int qtiles = prefill_qtiles(p, a.max_q, G);
+    const bool two = prefill_two_qtiles(p, qtiles, a.nkv, a.nseg);
+    if (a.stats && p.lazy == 1) {      // the counting instantiations of the shipped (per-tile lazy) kernels
+        if (a.hd == 128) return two ? launch_prefill<128, 2, 1, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, 1, true>(a, qtiles, scale_log2e, dense, s);
+        return two ? launch_prefill<72, 2, 1, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<72, 1, 1, true>(a, qtiles, scale_log2e, dense, s);
     }
-    if (a.hd == 128) return two ? launch_prefill<128, 2, false>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, false>(a, qtiles, scale_log2e, dense, s);
-    return two ? launch_prefill<72, 2, false>(a, qtiles, scale_log2e, dense, s) : launch_prefill<72, 1, false>(a, qtiles, scale_log2e, dense, s);
+    const int key = (a.hd == 128 ? 0 : 8) + (two ? 4 : 0) + p.lazy;
+    switch (key) {
+        case 0: return launch_prefill<128, 1, 0>(a, qtiles, scale_log2e, dense, s);
+        case 1: case 2: return launch_prefill<128, 1, 1>(a, qtiles, scale_log2e, dense, s);     // (one tile per wave: the paired form is the per-tile form)
+        case 4: return launch_prefill<128, 2, 0>(a, qtiles, scale_log2e, dense, s);
+        case 5: return launch_prefill<128, 2, 1>(a, qtiles, scale_log2e, dense, s);
+        case 6: return launch_prefill<128, 2, 2>(a, qtiles, scale_log2e, dense, s);
+        case 8: return launch_prefill<72, 1, 0>(a, qtiles, scale_log2e, dense, s);
+        case 9: case 10: return launch_prefill<72, 1, 1>(a, qtiles, scale_log2e, dense, s);
+        case 12: return launch_prefill<72, 2, 0>(a, qtiles, scale_log2e, dense, s);
+        default: return launch_prefill<72, 2, 1>(a, qtiles, scale_log2e, dense, s);     // (13, 14: the paired form needs more than the 128 registers of four waves per SIMD at hd 72 - it exists for hd 128 only)
+    }
 }

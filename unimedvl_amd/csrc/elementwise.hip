@@ -450,9 +450,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(const bf16_t* __restrict__
     for (int i = threadIdx.x; i < V; i += blockDim.x) {
         const float p = expf(rbf(bf2f(row[i]) / temp) - mx) / sum;   // fp32 probabilities, as autocast's softmax returns them
         const uint64_t h = splitmix64(key + (uint64_t)i);
-        const float u = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
-        const float q = -logf(u);                                           // Exp(1); q > 0 except u == 1
-        const float sc = q > 0.f ? p / q : (p > 0.f ? INFINITY : 0.f);
+        const float u = ((float)(h >> 41) + 0.5f) * (1.0f / 8388608.0f);    // [2^-24, 1 - 2^-24], exact in fp32 (the stream of gemm_epilogue.h::epi_gumbel_value)
+        const float q = fmaxf(-logf(u), 5.9604645e-8f);                     // Exp(1), q >= 5.9e-8 > 0: a token wins through p / q only
+        const float sc = p / q;
         if (sc > best || (sc == best && i < bidx)) { best = sc; bidx = i; }
     }
 #pragma unroll
@@ -852,8 +852,7 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
         hipLaunchKernelGGL(qkv_split_kernel, grid, block, 0, (hipStream_t)stream, a);
     } else {
         UMV_CHECK(a.hd == 128 || a.hd == 72, UMV_ERR_UNSUPPORTED, "qkv_post: head_dim %d unsupported (128, 72)", a.hd);
-        static int vec = -1;      // UMV_QKV_POST_VEC=0: the per-(token, head) wave for every size (A/B only)
-        if (vec < 0) { const char* e = getenv("UMV_QKV_POST_VEC"); vec = e ? atoi(e) : 1; }
+        static const int vec = [] { const char* e = getenv("UMV_QKV_POST_VEC"); return e ? atoi(e) : 1; }();      // UMV_QKV_POST_VEC=0: the per-(token, head) wave for every size (A/B only; read once, thread-safe)
         if (vec && a.hd == 128 && !a.qkv_partials && a.T >= 64 && (a.v_d_stride % 8) == 0) {
             const int64_t qk_items = (int64_t)a.T * (a.nq + a.nkv);
             hipLaunchKernelGGL(qk_post_vec128_kernel, dim3((unsigned)((qk_items + 15) / 16)), block, 0, (hipStream_t)stream, a);

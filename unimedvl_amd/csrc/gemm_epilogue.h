@@ -61,7 +61,9 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
 // Must be called by ALL lanes of the wave (shuffles); lanes without a valid element pass valid = false.
 // Sampling as an argmax (Gumbel-max): with temp > 0 the value whose key is taken is bf16(logit / temp) - ln(-ln(u)), u in (0, 1] from
 // splitmix64(row key + column) - argmax over a row = one draw from softmax(logits / temp) (bagel.py:1297-1299).  The generator and its
-// keying are umv_sample_bf16's (elementwise.hip); u == 1 gives +inf (that column wins), as q == 0 does there.
+// keying are umv_sample_bf16's (elementwise.hip).  u = (r + 0.5) 2^-23 with r the top 23 bits of the hash: strictly inside (0, 1) and exact in
+// fp32 (r + 0.5 needs 24 bits), so the noise stays finite (-ln(-ln u) in [-2.8, 16.6]) and a column can only win through its logit - with
+// u = 1 allowed (round 5) a column won with probability 2^-24 whatever its logit: ~1 % of the draws over a 152 k vocabulary.
 __device__ __forceinline__ uint64_t epi_splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -75,8 +77,9 @@ __device__ __forceinline__ uint64_t epi_sample_row_key(uint64_t seed, const int6
 __device__ __forceinline__ float epi_gumbel_value(float logit, float temp, uint64_t row_key, int n) {
     const float y = rbf(logit / temp);                                    // logits / temperature is a bf16 tensor in the reference
     const uint64_t h = epi_splitmix64(row_key + (uint64_t)n);
-    const float u = ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
-    return y - __logf(-__logf(u));
+    const float u = ((float)(h >> 41) + 0.5f) * (1.0f / 8388608.0f);      // [2^-24, 1 - 2^-24]
+    const float q = fmaxf(-__logf(u), 5.9604645e-8f);                     // Exp(1) draw, held at -ln(1 - 2^-24) whatever the fast log returns next to 1
+    return y - __logf(q);
 }
 __device__ __forceinline__ void epi_argmax_tile(uint64_t* __restrict__ partial, int64_t ld_partial, int m, int tile, int lane, bool valid,
                                                 int n0, int nend, const float* final, float temp = 0.f, uint64_t seed = 0, const int64_t* step_ptr = nullptr) {

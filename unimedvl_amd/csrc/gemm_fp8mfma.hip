@@ -293,8 +293,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled8_kernel(umv_gemm8_arg
 }
 
 static int raster8_gn() {   // n-blocks per strip of the tile order; UMV_GEMM_RASTER overrides (tuning only)
-    static int gn = -1;
-    if (gn < 0) { const char* e = getenv("UMV_GEMM_RASTER"); gn = e ? atoi(e) : 4; if (gn < 1) gn = 1; }
+    static const int gn = [] { const char* e = getenv("UMV_GEMM_RASTER"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();   // (read once, thread-safe)
     return gn;
 }
 
@@ -328,8 +327,7 @@ extern "C" int umv_gemm_fp8a8w(const umv_gemm8_args* ap, umv_stream_t stream) {
     if (a.M == 0) return UMV_OK;
     hipStream_t s = (hipStream_t)stream;
     const int KT = (a.K + 127) / 128, NTT = (a.N + 15) / 16;
-    static int force = -1;   // tuning only: UMV_GEMM8_TILE=<256|258|259|128>
-    if (force < 0) { const char* e = getenv("UMV_GEMM8_TILE"); force = e ? atoi(e) : 0; }
+    static const int force = [] { const char* e = getenv("UMV_GEMM8_TILE"); return e ? atoi(e) : 0; }();   // tuning only: UMV_GEMM8_TILE=<256|258|259|128> (read once, thread-safe)
     // Measured (tools/gemm_bench.py --fp8): the 256 x 256 tile wins once it gives >= ~144 workgroups (M=2048,N=4608: 69.6 vs
     // 77.4 us); below that the 256 x 128 tile with three stage buffers does (M=1024,N=3584,K=18944: 159 vs 251 us), and its
     // third buffer is worth 5-10% over two on every shape.

@@ -13,7 +13,7 @@
 //     are LITERAL registers a[4i : 4i+3] in the instruction text.  The compiler never sees them: it allocates only the
 //     fragment / address VGPRs, the kernel zeroes a[0:255] itself and moves them out 128 at a time for the epilogue.
 //     (What keeps this sound: the compiler uses AGPRs on its own only to spill, and this kernel's VGPR pressure is < 200 of
-//     256; tools/check_w4_isa.py greps the ISA for any v_accvgpr it did not write.)
+//     256; tests/test_host_cpu.py::test_w4_kernels_own_their_agprs greps the ISA for any v_accvgpr it did not write.)
 // Same MFMAs on the same operands in the same k order as the 8-wave tiles: results are bit-identical to them.
 #include "common.h"
 #include "../../include/unimedvl_hip.h"

@@ -464,10 +464,11 @@ def attn_workspace(nseg, nq, hd, max_q, nsplit, device):
 
 
 def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None, k_packed=None,
-              _entry=None):
+              _entry=None, variant=0, stats=None):
     """q: [T, nq*hd] or [T, nq, hd] rows, possibly a column slice of a wider buffer (row stride = q.stride(0)).
     k_packed: [T, nkv*hd] column slice holding K row-aligned with q (cache-less self-attention): the K slab is not read.
-    _entry: (function, checker, name) of another library taking the same umv_attn_args (experimental/ops.py; tests / tools only)."""
+    _entry: (function, checker, name) of another library taking the same umv_attn_args (experimental/ops.py; tests / tools only).
+    variant / stats: umv_attn_args.variant (_lib.ATTN_* bits) and the two uint32 rare-path counters (tests / A-B only)."""
     lib = _lib.load()
     _req(q, BF16, "q")
     if q.stride(-1) != 1 or (q.dim() == 3 and q.stride(1) != hd):
@@ -487,7 +488,8 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
         q=q.data_ptr(), out=out.data_ptr(), cu_q=cu_q.data_ptr(), kv_len=kv_len.data_ptr(),
         k_slab=k_ptr, vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
         causal=int(bool(causal)), max_q=max_q, max_kv=max_kv, nsplit=nsplit,
-        workspace=None if workspace is None else workspace.data_ptr(), q_row_stride=q.stride(0), k_key_stride=k_key_stride, **strides)
+        workspace=None if workspace is None else workspace.data_ptr(), q_row_stride=q.stride(0), k_key_stride=k_key_stride,
+        variant=int(variant), stats=None if stats is None else stats.data_ptr(), **strides)
     if _entry is not None:
         fn, chk, name = _entry
         chk(fn(C.byref(a), _stream()), name)

@@ -28,15 +28,19 @@ _LIN_FIELDS = ("wp", "bias", "w8", "scale", "w8m")
 
 
 def kernel_stamp():
-    """sha256 of PACK_LAYOUT_VERSION + the source of the packing kernels (csrc/pack.hip); None when the source is not there - a cache
-    whose maker cannot be identified is never trusted (and two unknowns never compare equal)"""
+    """sha256 of PACK_LAYOUT_VERSION + the sources that decide the bytes of a packed image: csrc/pack.hip and the headers it includes
+    (common.h: the bf16 rounding helpers; gemm_internal.h: cvt_fp8x16 behind the deq / w8 images; the public header).  None when a
+    source is not there - a cache whose maker cannot be identified is never trusted (and two unknowns never compare equal)"""
     import hashlib
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "pack.hip")
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256(PACK_LAYOUT_VERSION.encode())
     try:
-        with open(p, "rb") as f:
-            return hashlib.sha256(PACK_LAYOUT_VERSION.encode() + f.read()).hexdigest()
+        for rel in ("csrc/pack.hip", "csrc/common.h", "csrc/gemm_internal.h", "../include/unimedvl_hip.h"):
+            with open(os.path.join(here, rel), "rb") as f:
+                h.update(f.read())
     except OSError:
         return None
+    return h.hexdigest()
 
 
 def source_fingerprint(paths):
