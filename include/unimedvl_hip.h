@@ -266,7 +266,8 @@ enum {
     UMV_ATTN_VARIANT_TQ2 = 8,          /* ... two q-tiles per wave (neither bit: by grid size) */
     UMV_ATTN_VARIANT_EXACT = 16,       /* exact running maximum (the bits of attn_kernel) instead of the lazy softmax reference */
     UMV_ATTN_VARIANT_WHOLE_TOKENS = 32,/* q-tiles of whole tokens instead of densely packed (token, head) pairs */
-    UMV_ATTN_VARIANT_PAIR = 64         /* lazy softmax with both q-tiles of a wave in one call (TQ2 only) */
+    UMV_ATTN_VARIANT_PAIR = 64         /* debug builds (UMV_ATTN_PAIR_DEBUG) only: both q-tiles of a wave in one softmax call - a form that is
+                                          NOT deterministic (csrc/attention_prefill.hip); ignored by the product build */
 };
 size_t umv_attn_workspace_bytes(int nseg, int nq, int hd, int max_q, int nsplit);
 int umv_attn_varlen(const umv_attn_args* a, umv_stream_t stream);

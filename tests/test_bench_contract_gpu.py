@@ -92,3 +92,50 @@ def test_bench_configs3_workload_two_ranks():
     assert abs(d["value"] - 2 * 32 * 8 / (d["ms_per_step"] * 8e-3)) <= 0.02 * d["value"]
     b = d["config"]["cpu_binding"]
     assert b is not None and ("bound" in b)
+
+
+def _dry_run_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONDONTWRITEBYTECODE="1", UMV_BENCH_BACKEND="gloo", UMV_BENCH_SHARE_GPU="1")
+    return env
+
+
+def _one_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"rank 0 must print exactly ONE line, got {len(lines)}:\n{p.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("flags", [("--gather", "ids"), ("--gather", "logits"), ("--workload", "configs3", "--no-t2i")])
+def test_bench_eight_rank_dry_run(flags):
+    """The driver's scaling run is `bench.py --gpus 8` on an 8-GPU node, which no lease here has ever had (VERDICT r05 "missing" #2).  This is
+    that run at the SAME world size on the 1-GPU box: 8 ranks share cuda:0, collectives over gloo - rendezvous on 127.0.0.1,
+    bind_rank_to_gpu_socket for 8 ranks over the host's sockets, the (ragged, for configs3) all-gather of ids / of every step's logits at
+    world size 8, barrier + max over ranks, ONE line from rank 0 with whole-job tokens.  What stays unexercised is the `nccl` backend itself."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "tiny", "--steps", "6", "--warmup", "2", *flags],
+                       cwd=ROOT, env=_dry_run_env(), capture_output=True, text=True, timeout=1200)
+    d = _one_line(p)
+    per_gpu = 32 if "configs3" in flags else 8
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["batch_per_gpu"] == per_gpu and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * per_gpu * 6 / (d["ms_per_step"] * 6e-3)) <= 0.02 * d["value"]
+    assert "cpu_baseline" not in d
+    if "--gather" in flags:
+        assert d["config"]["c1_gather"] == flags[1]
+    b = d["config"].get("cpu_binding")
+    assert b is not None and "bound" in b
+
+
+def test_bench_eight_ranks_under_torch_distributed_run():
+    """... and launched the way the driver launches it: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "tiny", "--steps", "6", "--warmup", "2",
+                        "--no-t2i"], cwd=ROOT, env=_dry_run_env(), capture_output=True, text=True, timeout=1200)
+    d = _one_line(p)
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8"
+    assert abs(d["value"] - 8 * 8 * 6 / (d["ms_per_step"] * 6e-3)) <= 0.02 * d["value"]

@@ -131,10 +131,11 @@ def test_full_depth_vqa_single_request(fd):
         assert int(lg.argmax(-1)[0]) == pred
         print(f"  step {s}: |logit diff| max {d:.4f} (logit range {ref.abs().max().item():.2f}), cosine {cos:.6f}, oracle top-2 margin "
               f"{margin:.3f}, ids {pred} / {ref_pred}")
-        # measured on MI355X (round 3): 0.148 - 0.164 on logits of range 5.3 - 5.7, cosine 0.99957 - 0.99962
-        assert d <= 0.33, f"step {s}: logits differ by {d} (bound 0.33 = 2x measured)"
+        # measured on MI355X (round 3): 0.148 - 0.164 on logits of range 5.3 - 5.7, cosine 0.99957 - 0.99962.  The bound is the STATED
+        # tolerance (logits atol 0.25), not a multiple of the engine's own measurement
+        assert d <= 0.25, f"step {s}: logits differ by {d} (bound 0.25)"
         assert cos > 0.999, f"step {s}: logits cosine {cos}"
-        if margin > 0.33:
+        if margin > 0.25:
             assert pred == ref_pred, f"step {s}: greedy id {pred} vs oracle {ref_pred} despite a top-2 margin of {margin:.3f}"
             exact += 1
         # the engine's choice is always within the deviation bound of the oracle's best logit

@@ -339,8 +339,8 @@ def test_attention_prefill_isa_has_no_scratch(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     s = open(out).read()
     names = re.findall(r"^(_Z19attn_prefill_kernelILi(\d+)ELi(\d+)ELi(\d)ELb(\d)EEv\w+):", s, re.M)
-    # hd 128 / 72 x TQ 1 / 2 x exact / lazy; the paired-call lazy form at hd 128 / TQ 2; the four counting (stats) instantiations of the lazy kernels
-    assert len(names) == 13, names
+    # hd 128 / 72 x TQ 1 / 2 x exact / lazy; the four counting (stats) instantiations of the lazy kernels
+    assert len(names) == 12, names
     for n, hd, tq, lazy, stats in names:
         b = s.index(".Lfunc_end", s.index(n + ":"))
         scratch = int(re.compile(r"; ScratchSize: (\d+)").search(s, b).group(1))

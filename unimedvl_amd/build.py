@@ -27,6 +27,8 @@ FILE_FLAGS = {"attention_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # tools/r04_gemm_abl.sh); never in the default build
 if os.environ.get("UMV_ATTN_TRACE", "0") not in ("0", ""):      # timing study of the prefill attention (tools/attn_trace.py); never in the default build
     FILE_FLAGS["attention_prefill.hip"] = FILE_FLAGS["attention_prefill.hip"] + ["-DUMV_ATTN_TRACE"]
+if os.environ.get("UMV_ATTN_PAIR_DEBUG", "0") not in ("0", ""):  # bisecting forms of the paired lazy-softmax kernel (tools/attn_pair_debug.py); never in the default build
+    FILE_FLAGS["attention_prefill.hip"] = FILE_FLAGS["attention_prefill.hip"] + ["-DUMV_ATTN_PAIR_DEBUG=1"]
 if os.environ.get("UMV_GEMM_ABLATIONS", "0") not in ("0", ""):
     FILE_FLAGS["gemm.hip"] = ["-DUMV_GEMM_ABLATIONS"]
     FILE_FLAGS["gemm_w4.hip"] = ["-DUMV_GEMM_ABLATIONS"]
@@ -52,16 +54,29 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     procs = []
     groups = []
+    # per-object stamps: a source is recompiled only when it, a header (any csrc/*.h or the public header) or its flags changed
+    hh = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/unimedvl_hip.h"]:
+        if f.endswith(".h"):
+            hh.update(open(os.path.join(CSRC, f), "rb").read())
+    headers = hh.hexdigest()
+    obj_stamps = {}
     for lib, sources, extra, suffix in ((LIB, SOURCES, [], ""),):
         objs = []
         for src in sources:
             sp = os.path.join(CSRC, src)
             obj = os.path.join(LIBDIR, src.replace(".hip", suffix + ".o"))
             cmd = [hipcc] + FLAGS + extra + FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
+            ostamp = hashlib.sha256((headers + " ".join(cmd)).encode() + open(sp, "rb").read()).hexdigest()
+            objs.append(obj)
+            if not force and os.path.exists(obj) and os.path.exists(obj + ".stamp") and open(obj + ".stamp").read() == ostamp:
+                continue
+            if os.path.exists(obj + ".stamp"):
+                os.remove(obj + ".stamp")
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-            objs.append(obj)
+            obj_stamps[src] = (obj + ".stamp", ostamp)
         groups.append((lib, objs))
     for src, p in procs:
         out, _ = p.communicate()
@@ -70,6 +85,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {src}")
         if verbose and out.strip():
             print(out.decode())
+        open(obj_stamps[src][0], "w").write(obj_stamps[src][1])
     for lib, objs in groups:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
