@@ -224,6 +224,10 @@ typedef struct {
     int n_splits;
     int64_t split_stride;
     const uint16_t* qkv_bias;
+    /* Paged KV (optional): page_table as in umv_attn_args - token t goes to page page_table[tok_seg[t] * page_table_stride + tok_slot[t] / 256],
+     * in-page slot tok_slot[t] % 256; k_slab / vt_slab are the pools, *_seg_stride the page strides, v_d_stride = 256 */
+    const int32_t* page_table;
+    int page_table_stride;
 } umv_qkv_post_args;
 int umv_qkv_post(const umv_qkv_post_args* a, umv_stream_t stream);
 
@@ -258,7 +262,17 @@ typedef struct {
      * reference was set for the first time. */
     int variant;
     uint32_t* stats;
+    /* Paged KV (optional): page_table [nseg][page_table_stride] int32 - entry p of segment s is the pool page holding its keys
+     * p*256 .. p*256+255.  k_slab / vt_slab are then page POOLS, K [page][kv_head][256][hd], V^T [page][kv_head][hd][256]: k_seg_stride /
+     * v_seg_stride = elements per page, v_d_stride = 256.  (The LDS-shared prefill kernels take slabs only: a paged nsplit = 1 call runs
+     * on the per-wave kernel.)  wave_split = 2 / 4 (decode, max_q rows in one q-tile, hd 128): the waves of a workgroup split its key
+     * range and merge in LDS, so the same parallelism needs nsplit / wave_split partials for the combine. */
+    const int32_t* page_table;
+    int page_table_stride;
+    int wave_split;
 } umv_attn_args;
+#define UMV_KV_PAGE 256
+#define UMV_KV_PAGE_LOG2 8
 enum {
     UMV_ATTN_VARIANT_FORCE = 1,        /* the bits below replace the process policy (and its UMV_ATTN_* environment knobs) */
     UMV_ATTN_VARIANT_STREAM = 2,       /* the per-wave streaming kernel (attn_kernel) even where the LDS-shared kernels would run */

@@ -34,6 +34,7 @@ class QkvPostArgs(C.Structure):
         ("T", C.c_int), ("nq", C.c_int), ("nkv", C.c_int), ("hd", C.c_int), ("eps", C.c_float),
         ("fp32_chain", C.c_int),
         ("qkv_partials", C.c_void_p), ("n_splits", C.c_int), ("split_stride", C.c_int64), ("qkv_bias", C.c_void_p),
+        ("page_table", C.c_void_p), ("page_table_stride", C.c_int),
     ]
 
 
@@ -47,6 +48,7 @@ class AttnArgs(C.Structure):
         ("max_q", C.c_int), ("max_kv", C.c_int), ("nsplit", C.c_int), ("workspace", C.c_void_p),
         ("q_row_stride", C.c_int64), ("k_key_stride", C.c_int64),
         ("variant", C.c_int), ("stats", C.c_void_p),
+        ("page_table", C.c_void_p), ("page_table_stride", C.c_int), ("wave_split", C.c_int),
     ]
 
 

@@ -28,10 +28,16 @@ __device__ __forceinline__ bf16x8 mask_keys(bf16x8 v, int nvalid) {
     return o;
 }
 
-template <int HD>
+// WS > 1 (decode: ONE q-tile per (segment, kv head, split)): the workgroup's waves all own that q-tile and split the keys of the
+// workgroup's range among themselves in runs of 32-key blocks; their (O, m, l) triples meet in LDS (merge in wave order 0 .. wsplit-1,
+// wave w finishing the d-tiles dt = w, w + wsplit, ..) and the workgroup writes ONE partial (or the final rows).  PAGED = the K / V^T
+// operands are page pools addressed through umv_attn_args.page_table (pages of UMV_KV_PAGE = 256 keys; a 32-key block never straddles one).
+template <int HD, int WS>
 __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_log2e) {
+    constexpr int wsplit = WS;
     constexpr int KS = (HD + 31) / 32;   // k-steps over the head dim for S
     constexpr int DT = (HD + 15) / 16;   // 16-wide output d tiles
+    extern __shared__ __attribute__((aligned(16))) float attn_sm[];      // wsplit > 1: [wsplit][DT][64] f32x4 + [wsplit][16][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int G = a.nq / a.nkv;
@@ -39,7 +45,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     const int s = blockIdx.z;
     const int kh = blockIdx.y % a.nkv;
     const int split = blockIdx.y / a.nkv;
-    const int qt = blockIdx.x * (int)(blockDim.x >> 6) + wave;      // 1..4 q-tiles (waves) per workgroup, see the launcher
+    const int qt = wsplit > 1 ? (int)blockIdx.x : blockIdx.x * (int)(blockDim.x >> 6) + wave;      // 1..4 q-tiles (waves) per workgroup, see the launcher
     const int q0 = a.cu_q[s];
     const int Lq = a.cu_q[s + 1] - q0;
     const int Lk = a.kv_len[s];
@@ -73,9 +79,29 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
         int last_q = min(Lq - 1, qt * QPT + QPT - 1);
         kb_end = min(kb_end, Lk - Lq + last_q + 1);
     }
+    if (wsplit > 1) {     // this wave's run of 32-key blocks inside the workgroup's range
+        const int nblk = (max(kb_end - kb_begin, 0) + 31) >> 5;
+        const int per = (nblk + wsplit - 1) / wsplit;
+        const int b0 = kb_begin + wave * per * 32;
+        kb_end = min(kb_end, b0 + per * 32);
+        kb_begin = b0;
+    }
     const int64_t kstride = a.k_key_stride ? a.k_key_stride : HD;     // packed K (k_key_stride > 0): rows cu_q[s] .. of a [T, ...] buffer
-    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : s * a.k_seg_stride) + kh * a.k_head_stride;
-    const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
+    // slab form: one base per (segment, kv head); paged form: the base of the page holding block kb (key / column offsets then count
+    // from the page start: kpage0 = first key of that page)
+    const int32_t* ptab = a.page_table ? a.page_table + (int64_t)s * a.page_table_stride : nullptr;
+    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : (ptab ? 0 : s * a.k_seg_stride)) + kh * a.k_head_stride;
+    const bf16_t* vbase = a.vt_slab + (ptab ? 0 : s * a.v_seg_stride) + kh * a.v_head_stride;
+    auto k_of = [&](int kb, int& kpage0) -> const bf16_t* {
+        if (!ptab) { kpage0 = 0; return kbase; }
+        kpage0 = kb & ~(UMV_KV_PAGE - 1);
+        return kbase + (int64_t)ptab[kb >> UMV_KV_PAGE_LOG2] * a.k_seg_stride;
+    };
+    auto v_of = [&](int kb, int& kpage0) -> const bf16_t* {
+        if (!ptab) { kpage0 = 0; return vbase; }
+        kpage0 = kb & ~(UMV_KV_PAGE - 1);
+        return vbase + (int64_t)ptab[kb >> UMV_KV_PAGE_LOG2] * a.v_seg_stride;
+    };
 
     f32x4 o[DT];
 #pragma unroll
@@ -85,10 +111,12 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     // K fragments of a 32-key block; A row i=(lane&15) of tile t  <->  key kb + (i>>2)*8 + t*4 + (i&3)
     constexpr bool PREFETCH = HD <= 128;   // register budget: K(next) + V(cur) in flight while S/softmax run
     auto load_k = [&](int kb, bf16x8 (&kf)[2][PREFETCH ? KS : 1]) {
+        int kp0;
+        const bf16_t* kb_base = k_of(kb, kp0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-            const bf16_t* kp = kbase + (int64_t)min(key, Lk - 1) * kstride;   // keys past Lk are masked below: any valid row will do
+            const bf16_t* kp = kb_base + (int64_t)(min(key, Lk - 1) - kp0) * kstride;   // keys past Lk are masked below: any valid row will do
 #pragma unroll
             for (int ks = 0; ks < (PREFETCH ? KS : 1); ++ks) {
                 const int d = ks * 32 + g * 8;
@@ -104,11 +132,13 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     for (int kb = kb_begin; kb < kb_end; kb += 32) {
         // issue this block's V^T loads and the next block's K loads before any math
         bf16x8 vf[DTP];
+        int vp0;
+        const bf16_t* vb_base = v_of(kb, vp0);
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = dt * 16 + j;
-                vf[dt] = (d < HD) ? ldg_frag(vbase + (int64_t)d * a.v_d_stride + kb + g * 8) : zero_frag();
+                vf[dt] = (d < HD) ? ldg_frag(vb_base + (int64_t)d * a.v_d_stride + (kb - vp0) + g * 8) : zero_frag();
             }
             if (kb + 32 < kb_end) load_k(kb + 32, knext);
         }
@@ -122,7 +152,8 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
                 for (int ks = 0; ks < KS; ++ks) st[t] = mfma16(kcur[t][ks], qf[ks], st[t]);
             } else {   // large head_dim: stream the K fragments through the MFMA chain
                 const int key = kb + (j >> 2) * 8 + t * 4 + (j & 3);
-                const bf16_t* kp = kbase + (int64_t)min(key, Lk - 1) * kstride;   // keys past Lk are masked below: any valid row will do
+                int kp0;
+                const bf16_t* kp = k_of(kb, kp0) + (int64_t)(min(key, Lk - 1) - kp0) * kstride;   // keys past Lk are masked below: any valid row will do
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int d = ks * 32 + g * 8;
@@ -153,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
                 v = vf[dt];
             } else {
                 const int d = dt * 16 + j;
-                v = (d < HD) ? ldg_frag(vbase + (int64_t)d * a.v_d_stride + kb + g * 8) : zero_frag();
+                v = (d < HD) ? ldg_frag(vb_base + (int64_t)d * a.v_d_stride + (kb - vp0) + g * 8) : zero_frag();
             }
             if (partial) v = mask_keys(v, nvalid);
             // (pinning o[] in VGPRs with an asm MFMA, as attention_prefill.hip does, is bit-identical here too but buys nothing:
@@ -171,6 +202,38 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
             }
         }
     }
+    if constexpr (WS > 1) {
+        // merge the waves' (O, m, l) in LDS: wave order 0 .. WS-1 (fixed: the result does not depend on which wave finished first)
+        f32x4* smO = reinterpret_cast<f32x4*>(attn_sm);                       // [WS][DT][64]
+        float* smML = attn_sm + WS * DT * 64 * 4;                             // [WS][16][2]
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) smO[(wave * DT + dt) * 64 + lane] = o[dt];
+        if (g == 0) { smML[(wave * 16 + j) * 2] = m_run; smML[(wave * 16 + j) * 2 + 1] = l_run; }
+        __syncthreads();
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < WS; ++w) M = fmaxf(M, smML[(w * 16 + j) * 2]);
+        float wgt[WS], L = 0.f;
+#pragma unroll
+        for (int w = 0; w < WS; ++w) {
+            const float mw = smML[(w * 16 + j) * 2];
+            wgt[w] = (mw == -INFINITY) ? 0.f : umv_exp2(mw - M);
+            L += wgt[w] * smML[(w * 16 + j) * 2 + 1];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (dt % WS != wave) continue;          // this wave finishes (and stores) the d-tiles dt = wave, wave + WS, ..
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WS; ++w) {
+                const f32x4 ow = smO[(w * DT + dt) * 64 + lane];
+                acc.x += wgt[w] * ow.x; acc.y += wgt[w] * ow.y; acc.z += wgt[w] * ow.z; acc.w += wgt[w] * ow.w;
+            }
+            o[dt] = acc;
+        }
+        m_run = M;
+        l_run = L;
+    }
     if (!rvalid) return;
     const int64_t tok = q0 + qi;
     if (a.nsplit == 1) {
@@ -179,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + g * 4;
-            if (d + 3 < HD) {
+            if (d + 3 < HD && (WS == 1 || dt % WS == wave)) {
                 u32x2 pk;
                 pk.x = pack2bf(o[dt].x * inv, o[dt].y * inv);
                 pk.y = pack2bf(o[dt].z * inv, o[dt].w * inv);
@@ -193,9 +256,9 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + g * 4;
-            if (d + 3 < HD) *reinterpret_cast<f32x4*>(po + d) = o[dt];
+            if (d + 3 < HD && (WS == 1 || dt % WS == wave)) *reinterpret_cast<f32x4*>(po + d) = o[dt];
         }
-        if (g == 0) { po[HD] = m_run; po[HD + 1] = l_run; }
+        if (g == 0 && (WS == 1 || wave == 0)) { po[HD] = m_run; po[HD + 1] = l_run; }
     }
 }
 
@@ -222,18 +285,30 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     const int qtiles = (a.max_q + QPT - 1) / QPT;
     // one wave per q-tile, up to four per workgroup: a decode step (max_q = 1) has ONE q-tile per (segment, kv head, split), so its
     // workgroups are single waves (with 256 threads three of the four waves of each of the 544 workgroups only exited)
-    const int wpb = qtiles < 4 ? qtiles : 4;
-    dim3 grid((qtiles + wpb - 1) / wpb, a.nkv * a.nsplit, a.nseg), block(64 * wpb);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)a.hd);
     hipStream_t s = (hipStream_t)stream;
+    if (a.page_table) {
+        UMV_CHECK(a.page_table_stride > 0 && a.k_key_stride == 0, UMV_ERR_ARG, "attn: page_table needs page_table_stride > 0 and goes with pooled K (no k_key_stride)");
+        UMV_CHECK(a.v_d_stride == UMV_KV_PAGE, UMV_ERR_ARG, "attn: paged V^T rows are UMV_KV_PAGE = %d keys long (v_d_stride %lld)", UMV_KV_PAGE, (long long)a.v_d_stride);
+    }
+    // decode (one q-tile per (segment, kv head, split)) with wave_split = 2 / 4: the workgroup's waves split its keys, LDS merge
+    const int ws = (qtiles == 1 && (a.wave_split == 2 || a.wave_split == 4) && a.hd == 128) ? a.wave_split : 1;
+    // one wave per q-tile, up to four per workgroup: a decode step (max_q = 1) has ONE q-tile per (segment, kv head, split), so its
+    // workgroups are single waves (with 256 threads three of the four waves of each of the 544 workgroups only exited)
+    const int wpb = ws > 1 ? ws : (qtiles < 4 ? qtiles : 4);
+    dim3 grid(ws > 1 ? qtiles : (qtiles + wpb - 1) / wpb, a.nkv * a.nsplit, a.nseg), block(64 * wpb);
     if (a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72) && umv_attn_prefill_enabled(a.variant) && umv_attn_prefill_can_take(a))
         return umv_attn_prefill_launch(a, qtiles, scale_log2e, s);
-    if (a.hd == 128)
-        hipLaunchKernelGGL((attn_kernel<128>), grid, block, 0, s, a, scale_log2e);
+    if (a.hd == 128 && ws == 4)
+        hipLaunchKernelGGL((attn_kernel<128, 4>), grid, block, 4 * 8 * 1024 + 4 * 16 * 2 * 4, s, a, scale_log2e);
+    else if (a.hd == 128 && ws == 2)
+        hipLaunchKernelGGL((attn_kernel<128, 2>), grid, block, 2 * 8 * 1024 + 2 * 16 * 2 * 4, s, a, scale_log2e);
+    else if (a.hd == 128)
+        hipLaunchKernelGGL((attn_kernel<128, 1>), grid, block, 0, s, a, scale_log2e);
     else if (a.hd == 72)
-        hipLaunchKernelGGL((attn_kernel<72>), grid, block, 0, s, a, scale_log2e);
+        hipLaunchKernelGGL((attn_kernel<72, 1>), grid, block, 0, s, a, scale_log2e);
     else if (a.hd == 512 && a.nsplit == 1)   // VAE mid-block attention, single head of 512 (autoencoder.py:50-62)
-        hipLaunchKernelGGL((attn_kernel<512>), grid, block, 0, s, a, scale_log2e);
+        hipLaunchKernelGGL((attn_kernel<512, 1>), grid, block, 0, s, a, scale_log2e);
     else
         UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "attn: head_dim %d unsupported (128, 72, 512)", a.hd);
     UMV_LAUNCH_CHECK();

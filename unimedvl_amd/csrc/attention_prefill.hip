@@ -545,6 +545,7 @@ extern "C" int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q)
 // 2^31 - 1 bytes.  A (segment, kv head) whose K rows or V^T rows span more than that cannot be taken (keys beyond the clamp would read
 // as zeros, unmasked): umv_attn_varlen keeps such a call on the per-wave kernel, which uses 64-bit addresses.
 bool umv_attn_prefill_can_take(const umv_attn_args& a) {
+    if (a.page_table) return false;        // paged K / V^T pools: the per-wave kernel follows the page table
     const int64_t kstride = a.k_key_stride ? a.k_key_stride : a.hd;
     const int64_t kbytes = ((int64_t)a.max_kv + 64) * kstride * 2;      // (+ the blocks a stage may run past the last key)
     const int64_t vbytes = (int64_t)a.hd * a.v_d_stride * 2;

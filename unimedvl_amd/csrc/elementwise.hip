@@ -526,6 +526,17 @@ extern "C" int umv_patchify_f32_bf16(const float* img, int C, int H, int W, int 
     return UMV_OK;
 }
 
+// Where token t's K row / V^T column goes: the (segment, slot) pair of tok_seg / tok_slot, or - paged KV (umv_qkv_post_args.page_table) -
+// (pool page, slot inside the page); every kernel below addresses  base + seg * seg_stride + ... + slot  with these two values
+__device__ __forceinline__ int kv_seg(const umv_qkv_post_args& a, int t) {
+    const int seg = a.tok_seg[t];
+    return a.page_table ? a.page_table[(int64_t)seg * a.page_table_stride + (a.tok_slot[t] >> UMV_KV_PAGE_LOG2)] : seg;
+}
+__device__ __forceinline__ int kv_slot(const umv_qkv_post_args& a, int t) {
+    const int slot = a.tok_slot[t];
+    return a.page_table ? (slot & (UMV_KV_PAGE - 1)) : slot;
+}
+
 // ----------------------------------------------------------------------------- q/k norm + RoPE + KV append
 // One wavefront per (token, head) over the nq + 2*nkv heads of the fused QKV row.
 // Lane i owns elements i*EPL.. of the first half and the matching ones of the second
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(umv_qkv_post_args a) {
     const int t = (int)(item / nheads);
     const int h = (int)(item % nheads);
     const bf16_t* src = a.qkv + (int64_t)t * nheads * HD + (int64_t)h * HD;
-    const int seg = a.tok_seg[t], slot = a.tok_slot[t];
+    const int seg = kv_seg(a, t), slot = kv_slot(a, t);
     const bool is_q = h < a.nq, is_k = !is_q && h < a.nq + a.nkv;
     const bool act = lane < HALF;  // HD=128: all 64 lanes; HD=72: 36 lanes
     // The kernel is one dependent chain of memory round trips at decode sizes, so everything that does not depend on the
@@ -651,7 +662,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(umv_qkv_post_args a) {
     const int t = (int)(item / nheads);
     const int h = (int)(item % nheads);
     const bf16_t* src = a.qkv + (int64_t)t * nheads * HD + (int64_t)h * HD;
-    const int seg = a.tok_seg[t], slot = a.tok_slot[t];
+    const int seg = kv_seg(a, t), slot = kv_slot(a, t);
     if (h < a.nq) {
         bf16_t* dst = a.q_out + (int64_t)t * a.nq * HD + (int64_t)h * HD;
         for (int d = lane; d < HD; d += 64) dst[d] = src[d];
@@ -683,15 +694,15 @@ __global__ __launch_bounds__(256) void qkv_split_tile_kernel(umv_qkv_post_args a
             *reinterpret_cast<bf16x8*>(a.q_out + (int64_t)t * a.nq * HD + (int64_t)c * 8) = v;
         } else if (c < qk_ch) {
             const int h = (c - q_ch) / CH, cc = (c - q_ch) - h * CH;
-            *reinterpret_cast<bf16x8*>(a.k_slab + a.tok_seg[t] * a.k_seg_stride + h * a.k_head_stride + (int64_t)a.tok_slot[t] * HD + cc * 8) = v;
+            *reinterpret_cast<bf16x8*>(a.k_slab + kv_seg(a, t) * a.k_seg_stride + h * a.k_head_stride + (int64_t)kv_slot(a, t) * HD + cc * 8) = v;
         } else {
             *reinterpret_cast<bf16x8*>(vs + tt * nv + (c - qk_ch) * 8) = v;
         }
     }
     __syncthreads();
-    const int seg0 = a.tok_seg[t0], slot0 = a.tok_slot[t0];
+    const int seg0 = kv_seg(a, t0), slot0 = kv_slot(a, t0);
     bool run8 = nt == 8 && (slot0 & 7) == 0;
-    for (int tt = 1; tt < nt && run8; ++tt) run8 = a.tok_seg[t0 + tt] == seg0 && a.tok_slot[t0 + tt] == slot0 + tt;
+    for (int tt = 1; tt < nt && run8; ++tt) run8 = kv_seg(a, t0 + tt) == seg0 && kv_slot(a, t0 + tt) == slot0 + tt;
     if (run8) {
         for (int e = threadIdx.x; e < nv; e += 256) {
             const int h = e / HD, d = e - h * HD;
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(256) void qkv_split_tile_kernel(umv_qkv_post_args a
             const int tt = i / nv, e = i - tt * nv;
             const int h = e / HD, d = e - h * HD;
             const int t = t0 + tt;
-            a.vt_slab[a.tok_seg[t] * a.v_seg_stride + h * a.v_head_stride + (int64_t)d * a.v_d_stride + a.tok_slot[t]] = vs[tt * nv + e];
+            a.vt_slab[kv_seg(a, t) * a.v_seg_stride + h * a.v_head_stride + (int64_t)d * a.v_d_stride + kv_slot(a, t)] = vs[tt * nv + e];
         }
     }
 }
@@ -729,11 +740,11 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(umv_qkv_post_args a) {
     u32x4 r[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = i < nt ? *reinterpret_cast<const u32x4*>(src + (int64_t)i * nheads * HD) : (u32x4){0u, 0u, 0u, 0u};
-    const int seg0 = a.tok_seg[t0], slot0 = a.tok_slot[t0];
+    const int seg0 = kv_seg(a, t0), slot0 = kv_slot(a, t0);
     bool run8 = nt == 8 && (slot0 & 7) == 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
-        if (i < nt) run8 = run8 && a.tok_seg[t0 + i] == seg0 && a.tok_slot[t0 + i] == slot0 + i;
+        if (i < nt) run8 = run8 && kv_seg(a, t0 + i) == seg0 && kv_slot(a, t0 + i) == slot0 + i;
     const int h = e0 / HD, d0 = e0 - h * HD;                        // HD % 8 == 0: the 8 dims lie in one head
     if (run8) {
         bf16_t* dst = a.vt_slab + seg0 * a.v_seg_stride + h * a.v_head_stride + (int64_t)d0 * a.v_d_stride + slot0;
@@ -750,7 +761,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(umv_qkv_post_args a) {
         }
     } else {
         for (int i = 0; i < nt; ++i) {
-            bf16_t* dst = a.vt_slab + a.tok_seg[t0 + i] * a.v_seg_stride + h * a.v_head_stride + (int64_t)d0 * a.v_d_stride + a.tok_slot[t0 + i];
+            bf16_t* dst = a.vt_slab + kv_seg(a, t0 + i) * a.v_seg_stride + h * a.v_head_stride + (int64_t)d0 * a.v_d_stride + kv_slot(a, t0 + i);
 #pragma unroll
             for (int d = 0; d < 8; ++d) dst[(int64_t)d * a.v_d_stride] = (bf16_t)(r[i][d >> 1] >> ((d & 1) * 16));
         }
@@ -815,7 +826,7 @@ __global__ __launch_bounds__(256) void qk_post_vec128_kernel(umv_qkv_post_args a
     }
     if (!live) return;
     bf16_t* dst = is_q ? a.q_out + (int64_t)t * a.nq * HD + (int64_t)h * HD
-                       : a.k_slab + a.tok_seg[t] * a.k_seg_stride + (h - a.nq) * a.k_head_stride + (int64_t)a.tok_slot[t] * HD;
+                       : a.k_slab + kv_seg(a, t) * a.k_seg_stride + (h - a.nq) * a.k_head_stride + (int64_t)kv_slot(a, t) * HD;
     u32x2 p1, p2;
     p1.x = pack2bf(o1[0], o1[1]); p1.y = pack2bf(o1[2], o1[3]);
     p2.x = pack2bf(o2[0], o2[1]); p2.y = pack2bf(o2[2], o2[3]);
@@ -838,6 +849,8 @@ extern "C" int umv_qkv_post(const umv_qkv_post_args* ap, umv_stream_t stream) {
               "qkv_post: fp32 partial input needs the norm + RoPE path and 1 <= n_splits <= 64");
     UMV_CHECK(!a.q_norm_w || (a.k_norm_w && a.cos_tab && a.sin_tab && a.tok_pos), UMV_ERR_ARG, "qkv_post: norm without rope tables");
     UMV_CHECK(!a.expert || (a.q_norm_w_gen && a.k_norm_w_gen), UMV_ERR_ARG, "qkv_post: expert routing without gen norms");
+    UMV_CHECK(!a.page_table || (a.page_table_stride > 0 && a.v_d_stride == UMV_KV_PAGE), UMV_ERR_ARG,
+              "qkv_post: paged KV needs page_table_stride > 0 and V^T rows of UMV_KV_PAGE = %d keys (v_d_stride %lld)", UMV_KV_PAGE, (long long)a.v_d_stride);
     if (a.T == 0) return UMV_OK;
     int64_t items = (int64_t)a.T * (a.nq + 2 * a.nkv);
     dim3 grid((unsigned)((items + 3) / 4)), block(256);

@@ -46,7 +46,10 @@ class DecodeSession:
         self.B = B
         self.max_length = max_length
         nq, nkv, hd, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
-        cache.ensure(B, max(cache.lens) + max_length + 1, nkv, hd, dev)
+        if hasattr(cache, "ensure_tokens"):      # paged cache: pages for every slot's own decode horizon (the captured step reads the table)
+            cache.ensure_tokens([n + max_length + 1 for n in cache.lens], nkv, hd, dev)
+        else:
+            cache.ensure(B, max(cache.lens) + max_length + 1, nkv, hd, dev)
         self.lens0 = list(cache.lens)
         i32 = dict(dtype=torch.int32, device=dev)
         self.ids = start_tokens.to(device=dev, dtype=torch.int64).clone()
@@ -78,6 +81,9 @@ class DecodeSession:
             keys = 48 if B <= 8 else 64
             nsplit = max(1, min(32, (max_kv + keys - 1) // keys, max(1, (768 if 8 < B <= 32 else 1024) // (B * nkv))))
         self.nsplit = nsplit
+        # waves per attention workgroup splitting its key range with an LDS merge (umv_attn_args.wave_split: 0 = single-wave workgroups);
+        # UMV_DECODE_WSPLIT=2|4 for the A/B of profiles/r06_decode_wave_split.txt
+        self.wave_split = int(os.environ.get("UMV_DECODE_WSPLIT", "0") or 0)
         self.ws = ops.attn_workspace(B, nq, hd, 1, self.nsplit, dev) if self.nsplit > 1 else None
         self.max_kv = max_kv
         # static activations
@@ -161,7 +167,7 @@ class DecodeSession:
             ops.qkv_post(None if part else self.qkv, self.q, c.slabs[l], self.tok_seg, self.tok_slot, self.tok_pos, nq, nkv, hd,
                          cfg.rms_eps, lw.q_norm, lw.k_norm, cos_tab=w.cos, sin_tab=w.sin, **part)
             ops.attention(self.q, self.o, c.slabs[l], self.cu_q, self.kv_len, nq, nkv, hd, True, 1, self.max_kv,
-                          self.nsplit, self.ws)
+                          self.nsplit, self.ws, wave_split=self.wave_split)
             # ---- o_proj + residual, then the post-attention norm
             if so > 1:
                 ops.gemm_splitk(self.o, lw.o, self.p_h[:so], so)

@@ -131,12 +131,18 @@ class Qwen2MoT:
         assert sum(qlens) == T, "query_lens do not add up to the packed sequence"
         cache = past_key_values if past_key_values is not None else NaiveCache(cfg.layers)
         if cache.slabs is None:
-            cache.ensure(nseg, max(qlens), nkv, hd, dev)
+            if hasattr(cache, "ensure_tokens"):
+                cache.ensure_tokens([0] * nseg, nkv, hd, dev)
+            else:
+                cache.ensure(nseg, max(qlens), nkv, hd, dev)
         if key_values_lens is not None:
             kvl = _host_list(key_values_lens)
             if kvl != list(cache.lens):
                 raise ValueError(f"key_values_lens {kvl} disagree with the cache ({cache.lens})")
-        cache.ensure(nseg, max(c + q for c, q in zip(cache.lens, qlens)), nkv, hd, dev)
+        if hasattr(cache, "ensure_tokens"):      # paged cache: pages per segment, only where the context grows
+            cache.ensure_tokens([c + q for c, q in zip(cache.lens, qlens)], nkv, hd, dev)
+        else:
+            cache.ensure(nseg, max(c + q for c, q in zip(cache.lens, qlens)), nkv, hd, dev)
         if plan is None:
             plan = self.make_plan(qlens, packed_query_position_ids, cache.lens)
         elif plan.qlens != qlens:

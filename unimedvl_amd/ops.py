@@ -357,6 +357,32 @@ class KVSlab:
                     v_seg_stride=self.nkv * self.hd * self.cap, v_head_stride=self.hd * self.cap, v_d_stride=self.cap)
 
 
+KV_PAGE = 256      # keys per page of a paged KV pool (UMV_KV_PAGE)
+
+
+class PagedSlab:
+    """One layer's K / V^T page POOLS of a paged cache (kvcache.PagedCache): K [page][nkv][256][hd], V^T [page][nkv][hd][256], shared
+    by all segments through `table` ([nseg, max_pages] int32 on the device: entry p of segment s = the pool page of its keys p*256 ..).
+    Stands in for a KVSlab in qkv_post() / attention(): same strides() contract with "segment" read as "page"."""
+
+    __slots__ = ("k", "vt", "table", "nkv", "hd", "cap")
+
+    def __init__(self, npages, nkv, hd, device, table):
+        self.k = torch.zeros((npages, nkv, KV_PAGE, hd), dtype=BF16, device=device)
+        self.vt = torch.zeros((npages, nkv, hd, KV_PAGE), dtype=BF16, device=device)
+        self.table, self.nkv, self.hd = table, nkv, hd
+        self.cap = table.shape[1] * KV_PAGE          # longest context the table can describe
+
+    def strides(self):
+        return dict(k_seg_stride=self.nkv * KV_PAGE * self.hd, k_head_stride=KV_PAGE * self.hd,
+                    v_seg_stride=self.nkv * self.hd * KV_PAGE, v_head_stride=self.hd * KV_PAGE, v_d_stride=KV_PAGE)
+
+
+def _paging(slab):
+    t = getattr(slab, "table", None)
+    return {} if t is None else dict(page_table=t.data_ptr(), page_table_stride=t.stride(0))
+
+
 def quantize_act(x, M=None, row_idx=None):
     """Per-row e4m3 quantisation of bf16 activations (umv_quantize_act_fp8): returns (xq uint8 [M, ldq], scale f32 [M])."""
     lib = _lib.load()
@@ -454,7 +480,7 @@ def qkv_post(qkv, q_out, slab, tok_seg, tok_slot, tok_pos, nq, nkv, hd, eps=1e-6
         q_norm_w_gen=None if q_norm_gen is None else q_norm_gen.data_ptr(),
         k_norm_w_gen=None if k_norm_gen is None else k_norm_gen.data_ptr(),
         cos_tab=None if cos_tab is None else cos_tab.data_ptr(), sin_tab=None if sin_tab is None else sin_tab.data_ptr(),
-        T=T, nq=nq, nkv=nkv, hd=hd, eps=eps, fp32_chain=int(fp32_chain), **slab.strides())
+        T=T, nq=nq, nkv=nkv, hd=hd, eps=eps, fp32_chain=int(fp32_chain), **slab.strides(), **_paging(slab))
     check(lib.umv_qkv_post(C.byref(a), _stream()), "umv_qkv_post")
 
 
@@ -464,7 +490,7 @@ def attn_workspace(nseg, nq, hd, max_q, nsplit, device):
 
 
 def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, nsplit=1, workspace=None, k_packed=None,
-              _entry=None, variant=0, stats=None):
+              _entry=None, variant=0, stats=None, wave_split=0):
     """q: [T, nq*hd] or [T, nq, hd] rows, possibly a column slice of a wider buffer (row stride = q.stride(0)).
     k_packed: [T, nkv*hd] column slice holding K row-aligned with q (cache-less self-attention): the K slab is not read.
     _entry: (function, checker, name) of another library taking the same umv_attn_args (experimental/ops.py; tests / tools only).
@@ -489,7 +515,7 @@ def attention(q, out, slab, cu_q, kv_len, nq, nkv, hd, causal, max_q, max_kv, ns
         k_slab=k_ptr, vt_slab=slab.vt.data_ptr(), nseg=kv_len.numel(), nq=nq, nkv=nkv, hd=hd,
         causal=int(bool(causal)), max_q=max_q, max_kv=max_kv, nsplit=nsplit,
         workspace=None if workspace is None else workspace.data_ptr(), q_row_stride=q.stride(0), k_key_stride=k_key_stride,
-        variant=int(variant), stats=None if stats is None else stats.data_ptr(), **strides)
+        variant=int(variant), stats=None if stats is None else stats.data_ptr(), wave_split=int(wave_split), **strides, **_paging(slab))
     if _entry is not None:
         fn, chk, name = _entry
         chk(fn(C.byref(a), _stream()), name)

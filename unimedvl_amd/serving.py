@@ -27,7 +27,7 @@ import torch
 from . import ops
 
 from .decode import DecodeSession
-from .kvcache import NaiveCache
+from .kvcache import NaiveCache, PagedCache
 
 
 @dataclass
@@ -42,9 +42,14 @@ class _Request:
 class ContinuousBatcher:
     def __init__(self, model, tokenizer, new_token_ids, image_transform, slots: int = 8, max_context: int = 2048,
                  max_new_tokens: int = 256, check_every: int = 16, do_sample: bool = False, temperature: float = 1.0,
-                 use_graph: bool = True, growable: bool = True, context_limit: Optional[int] = None):
+                 use_graph: bool = True, growable: bool = True, context_limit: Optional[int] = None, paged: bool = False,
+                 pool_pages: Optional[int] = None):
         """max_context: the context (prompt + images) the slots are RESERVED for; with growable=True longer requests enlarge
-        the cache (up to context_limit tokens of context when given), with growable=False they are refused."""
+        the cache (up to context_limit tokens of context when given), with growable=False they are refused.
+        paged=True: block-table KV (kvcache.PagedCache) instead of slabs - the slots draw 256-token pages from ONE pool of `pool_pages`
+        pages per layer (default: what max_context + max_new_tokens needs for every slot, plus as much again), a request of any length
+        up to context_limit (default 32 768) is admitted without re-allocating or re-capturing anything, and a finished request returns
+        its pages.  Same answers as the slab cache (tests/test_paged_kv_gpu.py)."""
         self.model, self.tokenizer, self.new_token_ids, self.image_transform = model, tokenizer, new_token_ids, image_transform
         self.device = model.device
         self.slots, self.check_every = int(slots), int(check_every)
@@ -53,9 +58,14 @@ class ContinuousBatcher:
         self.growable, self.context_limit = bool(growable), context_limit
         self._grew = False
         cfg = model.cfg
-        self.cache = NaiveCache(cfg.layers)
-        self.cache.reserve(self.slots, self.max_context + self.default_new + self.check_every + 8, cfg.kv_heads, cfg.head_dim,
-                           model.device)
+        self.paged = bool(paged)
+        per_slot = self.max_context + self.default_new + self.check_every + 8
+        if self.paged:
+            pages = 2 * self.slots * ((per_slot + ops.KV_PAGE - 1) // ops.KV_PAGE) + 1 if pool_pages is None else int(pool_pages)
+            self.cache = PagedCache(cfg.layers, pool_pages=pages, max_context=(context_limit or 32768) + self.default_new + self.check_every + 8)
+        else:
+            self.cache = NaiveCache(cfg.layers)
+        self.cache.reserve(self.slots, per_slot, cfg.kv_heads, cfg.head_dim, model.device)
         self.queue: Deque[_Request] = deque()
         self.results: Dict[int, str] = {}
         self._next_id = 0
@@ -81,7 +91,8 @@ class ContinuousBatcher:
         bos, eos = self.new_token_ids["bos_token_id"], self.new_token_ids["eos_token_id"]
         active: List[Optional[_Request]] = [None] * B
         state = [(bos, 0, 0)] * B                       # (next token, kv_len, rope position) per slot
-        cache.lens = [0] * B
+        for b in range(B):
+            self._free_slot(b)
         first = []
         for b in range(B):
             if self.queue:
@@ -106,6 +117,9 @@ class ContinuousBatcher:
                 self._between_rounds()
                 continue
             k = self.check_every
+            if self.paged:      # pages for this round's tokens (the captured step reads the table from device memory; an idle slot, parked
+                cfg = m.cfg     # at the start of its segment, keeps one page of its own to write to)
+                cache.ensure_tokens([n + k + 1 for n in cache.lens], cfg.kv_heads, cfg.head_dim, self.device)
             sess.rewind_outputs()
             sess.step(k)
             self._between_rounds()                      # (queued behind the decode steps; the host reads the ids after both)
@@ -133,7 +147,7 @@ class ContinuousBatcher:
                     continue
                 self._finish(req)
                 active[b] = None
-                cache.lens[b] = 0
+                self._free_slot(b)
                 if self.queue:
                     active[b] = self.queue.popleft()
                     freed.append(b)
@@ -153,6 +167,13 @@ class ContinuousBatcher:
     def _other_work(self) -> bool:
         return False
 
+    def _free_slot(self, b: int):
+        """slot b's request is done: forget its context (a paged cache gets its pages back)"""
+        if self.paged:
+            self.cache.release(b)
+        else:
+            self.cache.lens[b] = 0
+
     def _between_rounds(self):
         pass
 
@@ -160,7 +181,7 @@ class ContinuousBatcher:
     def _prefill(self, b: int, req: _Request):
         """Image(s) then the prompt into slot b (Bagel.chat's order, bagel.py:1321-1392); returns the slot's decode state."""
         m = self.model
-        self.cache.lens[b] = 0
+        self._free_slot(b)
         view = self.cache.view_segments(b, b + 1)
         view.lens = [0]
         cap = view.cap
@@ -202,7 +223,7 @@ class ContinuousBatcher:
         m, cache, B = self.model, self.cache, self.slots
         cap = cache.cap
         for b in slots:
-            cache.lens[b] = 0
+            self._free_slot(b)
         k = len(slots)
         kvl, rope = [0] * k, [0] * k
 
@@ -236,6 +257,10 @@ class ContinuousBatcher:
         same, or - growable - the enlarged one (the pooled cache is re-allocated HERE, before the forward that would write
         past the old slabs; run() re-captures the decode session afterwards)."""
         need = ctx_tokens + req.max_new_tokens + self.check_every + 1
+        if self.paged:          # pages are taken as the context grows; the only bound is the page table's reach
+            if need > cap:
+                raise ValueError(f"request {req.rid}: {need} tokens of context + answer exceed the page table's reach of {cap}")
+            return cap
         if ctx_tokens <= self.max_context and need <= cap:
             return cap
         if not self.growable:
