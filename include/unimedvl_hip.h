@@ -264,8 +264,8 @@ typedef struct {
     uint32_t* stats;
     /* Paged KV (optional): page_table [nseg][page_table_stride] int32 - entry p of segment s is the pool page holding its keys
      * p*256 .. p*256+255.  k_slab / vt_slab are then page POOLS, K [page][kv_head][256][hd], V^T [page][kv_head][hd][256]: k_seg_stride /
-     * v_seg_stride = elements per page, v_d_stride = 256.  (The LDS-shared prefill kernels take slabs only: a paged nsplit = 1 call runs
-     * on the per-wave kernel.)  wave_split = 2 / 4 (decode, max_q rows in one q-tile, hd 128): the waves of a workgroup split its key
+     * v_seg_stride = elements per page, v_d_stride = 256; a pool is at most 2 GiB (32-bit offsets of the LDS-shared prefill kernels, whose
+     * PAGED instantiations give the slab call's bits; hd 72 / exact-maximum variants of a paged call run on the per-wave kernel).  wave_split = 2 / 4 (decode, max_q rows in one q-tile, hd 128): the waves of a workgroup split its key
      * range and merge in LDS, so the same parallelism needs nsplit / wave_split partials for the combine. */
     const int32_t* page_table;
     int page_table_stride;

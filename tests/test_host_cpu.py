@@ -338,10 +338,10 @@ def test_attention_prefill_isa_has_no_scratch(tmp_path):
                         "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     s = open(out).read()
-    names = re.findall(r"^(_Z19attn_prefill_kernelILi(\d+)ELi(\d+)ELi(\d)ELb(\d)EEv\w+):", s, re.M)
-    # hd 128 / 72 x TQ 1 / 2 x exact / lazy; the four counting (stats) instantiations of the lazy kernels
-    assert len(names) == 12, names
-    for n, hd, tq, lazy, stats in names:
+    names = re.findall(r"^(_Z19attn_prefill_kernelILi(\d+)ELi(\d+)ELi(\d)ELb(\d)ELb(\d)EEv\w+):", s, re.M)
+    # hd 128 / 72 x TQ 1 / 2 x exact / lazy; the four counting (stats) instantiations of the lazy kernels; the two paged hd-128 lazy kernels
+    assert len(names) == 14, names
+    for n, hd, tq, lazy, stats, paged in names:
         b = s.index(".Lfunc_end", s.index(n + ":"))
         scratch = int(re.compile(r"; ScratchSize: (\d+)").search(s, b).group(1))
         occ = int(re.compile(r"; Occupancy: (\d+)").search(s, b).group(1))

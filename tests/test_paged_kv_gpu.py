@@ -112,10 +112,28 @@ def test_paged_prefill_attention_and_qkv_post(ops):
     cu = torch.tensor([0, 200, 329, 406], dtype=torch.int32).cuda()
     kvl = torch.tensor(lens, dtype=torch.int32).cuda()
     from unimedvl_amd import _lib as L
-    ref = torch.zeros(T, nq, hd, dtype=BF16, device="cuda")
-    ops.attention(q1, ref, slab, cu, kvl, nq, nkv, hd, True, max(qlens), max(lens), variant=L.ATTN_FORCE | L.ATTN_STREAM)
-    out = torch.zeros_like(ref)
-    ops.attention(q1, out, ps, cu, kvl, nq, nkv, hd, True, max(qlens), max(lens))        # (a paged call runs on the per-wave kernel)
+    # the library's own policy (LDS-shared lazy kernels, their PAGED instantiation), TQ = 1 and 2, and the per-wave kernel: paged == slab, bit for bit
+    for variant in (0, L.ATTN_FORCE | L.ATTN_TQ1, L.ATTN_FORCE | L.ATTN_TQ2, L.ATTN_FORCE | L.ATTN_STREAM):
+        ref = torch.zeros(T, nq, hd, dtype=BF16, device="cuda")
+        ops.attention(q1, ref, slab, cu, kvl, nq, nkv, hd, True, max(qlens), max(lens), variant=variant)
+        out = torch.zeros_like(ref)
+        ops.attention(q1, out, ps, cu, kvl, nq, nkv, hd, True, max(qlens), max(lens), variant=variant)
+        assert torch.isfinite(out.float()).all() and float(out.float().abs().max()) > 0
+        assert torch.equal(out, ref), f"variant {variant}: paged prefill attention differs from the slab form"
+    # a long, non-causal span over several pages (8 x 1026 image spans on top of 300 cached keys: TQ = 2 by policy)
+    lens2 = [300 + 1026] * 8
+    slab2 = ops.KVSlab(8, nkv, 1344, hd, "cuda")
+    slab2.k.copy_(torch.randn(slab2.k.shape, generator=g, device="cuda").to(BF16))
+    slab2.vt.copy_(torch.randn(slab2.vt.shape, generator=g, device="cuda").to(BF16))
+    ps2 = _paged_copy(ops, slab2, lens2, 11)
+    qq = torch.randn(8 * 1026, nq, hd, generator=g, device="cuda").to(BF16)
+    cu2 = torch.arange(0, 9 * 1026, 1026, dtype=torch.int32).cuda()
+    kvl2 = torch.tensor(lens2, dtype=torch.int32).cuda()
+    assert L.load().umv_attn_prefill_tq(8, nq, nkv, hd, 1026) == 2
+    ref = torch.zeros_like(qq)
+    ops.attention(qq, ref, slab2, cu2, kvl2, nq, nkv, hd, False, 1026, 1326)
+    out = torch.zeros_like(qq)
+    ops.attention(qq, out, ps2, cu2, kvl2, nq, nkv, hd, False, 1026, 1326)
     assert torch.equal(out, ref)
 
 
@@ -167,11 +185,14 @@ def test_paged_cache_engine_and_snapshots(tiny_weights):
     assert s2.lens == kvl
     for l in range(cfg.layers):
         assert torch.equal(s1.packed_keys(l), s2.packed_keys(l)) and torch.equal(s1.packed_values(l), s2.packed_values(l))
+    # page accounting: 2 + 1 + 3 prefix pages; the decode appended to the shared, partially filled last page of each segment, which
+    # copied that page (3 more) and left the originals to the snapshot - whose own decode then writes into pages it alone holds
     used = c2.pages_in_use()
+    assert used == (2 + 1 + 3) + 3, used
     gs = model.prepare_start_tokens(kvl, rope, NEW_TOKEN_IDS)
     ids3, _ = model.generate_text(past_key_values=s2, max_length=20, return_logits=True, **gs)
     assert torch.equal(ids3, ids1)
-    assert c2.pages_in_use() > used, "appending to a snapshot must copy its shared last pages, not write into them"
+    assert c2.pages_in_use() == used
     for l in range(cfg.layers):          # ... and the first cache is untouched by the snapshot's decode
         assert torch.equal(c1.packed_keys(l), c2.packed_keys(l))
     for s in range(3):

@@ -150,7 +150,10 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
 // LAZY: 0 = exact running maximum, 1 = lazy reference (one softmax call per q-tile), 2 = lazy, both tiles in one call.  STATS: the kernel
 // also counts its rare-path events into umv_attn_args.stats (a separate instantiation, selected when stats != NULL: the counters cost the
 // hd-72 two-tile kernel the last of its 128 registers; same arithmetic, and the tests compare its output with the plain kernel's bit for bit)
-template <int HD, int TQ, int LAZY, bool STATS = false>
+// PAGED: K / V^T are page pools behind umv_attn_args.page_table (a separate instantiation of the shipped lazy kernels: the slab kernels are
+// not touched; same arithmetic in the same block order, so a paged call gives the slab call's bits).  A stage's DMA offset becomes
+// page base + offset inside the page; a 32-key block (and a two-block stage) never straddles a 256-key page.
+template <int HD, int TQ, int LAZY, bool STATS = false, bool PAGED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STATS ? 1 : ATTN_PREFILL_WAVES(HD, TQ)))) void attn_prefill_kernel(umv_attn_args a, float scale_log2e, int dense) {
     constexpr int KS = (HD + 31) / 32;
     constexpr int DT = (HD + 15) / 16;
@@ -210,8 +213,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STATS ? 1 :
     }
     const int nstages = (blk_end + 32 * NB - 1) / (32 * NB);
     const int64_t kstride = a.k_key_stride ? a.k_key_stride : HD;     // packed K (k_key_stride > 0): rows cu_q[s] .. of a [T, ...] buffer
-    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : s * a.k_seg_stride) + kh * a.k_head_stride;
-    const bf16_t* vbase = a.vt_slab + s * a.v_seg_stride + kh * a.v_head_stride;
+    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : (PAGED ? 0 : s * a.k_seg_stride)) + kh * a.k_head_stride;
+    const bf16_t* vbase = a.vt_slab + (PAGED ? 0 : s * a.v_seg_stride) + kh * a.v_head_stride;
+    const int32_t* ptab = PAGED ? a.page_table + (int64_t)s * a.page_table_stride : nullptr;
+    const uint32_t kpage_bytes = PAGED ? (uint32_t)(a.k_seg_stride * 2) : 0u, vpage_bytes = PAGED ? (uint32_t)(a.v_seg_stride * 2) : 0u;
 
     // ---- staging: fragment f of a stage (K fragments (t, ks) of its 32-key blocks, then their V^T fragments) is fetched by wave f % 4
     // with ONE buffer_load_dwordx4 ... lds: the lane's byte offset inside this (segment, kv head)'s K rows / V^T rows is a kernel
@@ -222,9 +227,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STATS ? 1 :
     // zeroes them (as before); a fragment that runs past the end of a V^T row reads the next row's head - keys >= Lk, masked too.
     constexpr int NFR = (NB * FB + 3) / 4;         // fragments per wave and stage
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0,
-                                                                         (int)min((int64_t)Lk * kstride * 2, (int64_t)0x7FFFFFFF), 0x00020000);
+                                                                         PAGED ? 0x7FFFFFFF : (int)min((int64_t)Lk * kstride * 2, (int64_t)0x7FFFFFFF), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0,
-                                                                         (int)min((int64_t)HD * a.v_d_stride * 2, (int64_t)0x7FFFFFFF), 0x00020000);
+                                                                         PAGED ? 0x7FFFFFFF : (int)min((int64_t)HD * a.v_d_stride * 2, (int64_t)0x7FFFFFFF), 0x00020000);
     uint32_t voff[NFR];
 #pragma unroll
     for (int i = 0; i < NFR; ++i) {
@@ -249,8 +254,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STATS ? 1 :
                 const uint32_t blk = (uint32_t)(sidx * NB + b);
                 const uint32_t off = voff[i];          // (a local: passing the array element makes the host pass drop the kernel's stub)
                 char* dst = smem + buf * STAGE + f * 1024;
-                if (ff < FK) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (attn_lds_ptr_t)dst, 16, off, blk * kstep, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (attn_lds_ptr_t)dst, 16, off, blk * 64u, 0, 0);
+                uint32_t ks_off = blk * kstep, vs_off = blk * 64u;
+                if constexpr (PAGED) {                 // (uniform scalar load; the table's 64-byte lines hold 16 pages = 128 blocks)
+                    const uint32_t pg = (uint32_t)ptab[blk >> (UMV_KV_PAGE_LOG2 - 5)], inpage = blk & ((UMV_KV_PAGE >> 5) - 1);
+                    ks_off = pg * kpage_bytes + inpage * kstep;
+                    vs_off = pg * vpage_bytes + inpage * 64u;
+                }
+                if (ff < FK) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (attn_lds_ptr_t)dst, 16, off, ks_off, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (attn_lds_ptr_t)dst, 16, off, vs_off, 0, 0);
             }
         }
     };
@@ -503,15 +514,15 @@ static AttnPolicy attn_policy(int variant) {
 }
 bool umv_attn_prefill_enabled(int variant) { return attn_policy(variant).shared != 0; }
 
-template <int HD, int TQ, int LAZY, bool STATS = false>
+template <int HD, int TQ, int LAZY, bool STATS = false, bool PAGED = false>
 static int launch_prefill(const umv_attn_args& a, int qtiles, float scale_log2e, int dense, hipStream_t s) {
     constexpr int KS = (HD + 31) / 32, DT = (HD + 15) / 16;
     constexpr int lds = 2 * ATTN_PREFILL_NB(HD, TQ) * (2 * KS + DT) * 1024;
     static bool attr[UMV_MAX_DEVICES] = {};
     if (umv_first_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ, LAZY, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<HD, TQ, LAZY, STATS, PAGED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     dim3 grid((qtiles + 4 * TQ - 1) / (4 * TQ), a.nkv, a.nseg);
-    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY, STATS>), grid, dim3(256), lds, s, a, scale_log2e, dense);
+    hipLaunchKernelGGL((attn_prefill_kernel<HD, TQ, LAZY, STATS, PAGED>), grid, dim3(256), lds, s, a, scale_log2e, dense);
     UMV_LAUNCH_CHECK();
     return UMV_OK;
 }
@@ -545,7 +556,8 @@ extern "C" int umv_attn_prefill_tq(int nseg, int nq, int nkv, int hd, int max_q)
 // 2^31 - 1 bytes.  A (segment, kv head) whose K rows or V^T rows span more than that cannot be taken (keys beyond the clamp would read
 // as zeros, unmasked): umv_attn_varlen keeps such a call on the per-wave kernel, which uses 64-bit addresses.
 bool umv_attn_prefill_can_take(const umv_attn_args& a) {
-    if (a.page_table) return false;        // paged K / V^T pools: the per-wave kernel follows the page table
+    if (a.page_table)       // paged pools: 32-bit DMA offsets reach 2 GiB from the pool base - the caller promises page ids below that (kvcache.PagedCache
+        return a.hd == 128 && a.k_key_stride == 0 && attn_policy(a.variant).lazy == 1 && !a.stats;      // checks); hd 128 lazy kernels only
     const int64_t kstride = a.k_key_stride ? a.k_key_stride : a.hd;
     const int64_t kbytes = ((int64_t)a.max_kv + 64) * kstride * 2;      // (+ the blocks a stage may run past the last key)
     const int64_t vbytes = (int64_t)a.hd * a.v_d_stride * 2;
@@ -558,6 +570,8 @@ int umv_attn_prefill_launch(const umv_attn_args& a, int /*qtiles of the per-wave
     const int dense = attn_dense(p, G) ? 1 : 0;
     const int qtiles = prefill_qtiles(p, a.max_q, G);
     const bool two = prefill_two_qtiles(p, qtiles, a.nkv, a.nseg);
+    if (a.page_table)
+        return two ? launch_prefill<128, 2, 1, false, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, 1, false, true>(a, qtiles, scale_log2e, dense, s);
     if (a.stats && p.lazy == 1) {      // the counting instantiations of the shipped (per-tile lazy) kernels
         if (a.hd == 128) return two ? launch_prefill<128, 2, 1, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<128, 1, 1, true>(a, qtiles, scale_log2e, dense, s);
         return two ? launch_prefill<72, 2, 1, true>(a, qtiles, scale_log2e, dense, s) : launch_prefill<72, 1, 1, true>(a, qtiles, scale_log2e, dense, s);

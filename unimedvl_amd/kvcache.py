@@ -177,6 +177,8 @@ class _PagePool:
     """Allocator state shared by a PagedCache and its views / snapshots: the per-layer pools, the free list, page reference counts."""
 
     def __init__(self, num_layers, npages, nkv, hd, device, nseg, max_pages):
+        if npages * nkv * ops.KV_PAGE * hd * 2 > 2 ** 31 - 1:       # the LDS-shared prefill kernels reach a page through a 32-bit byte offset
+            raise ValueError(f"paged KV pool of {npages} pages x {nkv * ops.KV_PAGE * hd * 2} bytes exceeds 2 GiB per layer and operand")
         self.table = torch.zeros((nseg, max_pages), dtype=torch.int32, device=device)      # entry p of segment s: pool page of keys p*256..
         self.host_table = [[] for _ in range(nseg)]                                       # pages each segment owns, in order
         self.slabs = [ops.PagedSlab(npages, nkv, hd, device, self.table) for _ in range(num_layers)]
