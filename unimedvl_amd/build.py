@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # AGPRs and moves them out and back around every rescale)
 FILE_FLAGS = {"attention_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # UMV_GEMM_ABLATIONS=1: also instantiate the tiled GEMM's timing-only ablations and its 32x32x16 variant (UMV_GEMM_TILE=966x / 566...,
-# tools/r04_gemm_abl.sh); never in the default build
+# git history: tools/r04_gemm_abl.sh); never in the default build
 if os.environ.get("UMV_ATTN_TRACE", "0") not in ("0", ""):      # timing study of the prefill attention (tools/attn_trace.py); never in the default build
     FILE_FLAGS["attention_prefill.hip"] = FILE_FLAGS["attention_prefill.hip"] + ["-DUMV_ATTN_TRACE"]
 if os.environ.get("UMV_ATTN_PAIR_DEBUG", "0") not in ("0", ""):  # bisecting forms of the paired lazy-softmax kernel (tools/attn_pair_debug.py); never in the default build

@@ -811,7 +811,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_tiled_kernel(umv_gemm_args 
     // lanes the addresses  tile[(lane >> 4) & 1] + ((2h + (lane >> 5)) * 16 + (lane & 15)) * 16  (h = k half of the step) - the
     // four quarter-wave groups of a ds_read_b128 still cover 256 distinct bytes mod 256 each: conflict free.  Half the matrix
     // instructions per k-step (16 of 8 passes each instead of 32 of 4 for the 256 x 256 tile), the accumulators stay 128 registers.
-    // SCHED >> 4 = ablation number (TIMING ONLY, results are wrong; UMV_GEMM_TILE=966x, tools/r04_gemm_sweep.sh): 1 no LDS-DMA pieces
+    // SCHED >> 4 = ablation number (TIMING ONLY, results are wrong; UMV_GEMM_TILE=966x, profiles/r04_gemm_ablations.txt): 1 no LDS-DMA pieces
     // in the main loop, 2 every other fragment read, 3 no MFMAs, 4 no barrier, 5 MFMAs + barrier only, 6 x pieces read contiguous
     // KiB instead of 16 rows x 64 B, 7 no x pieces, 8 no W pieces
     constexpr int ABL = SCHED >> 4, SCH = SCHED & 15;
