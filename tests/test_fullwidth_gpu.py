@@ -285,14 +285,14 @@ def test_configs2_t2i_256_fifty_timesteps(fw):
     """configs[2] AS WRITTEN: 50 diffusion timesteps = 49 Euler steps (bagel.py:937-986; the default of
     interactive_image_generator.py:63), 256 x 256, the reference's default guidance (cfg_text 4.0, cfg_img 1.5, interval (0.4, 1],
     global renorm, shift 3.0) - VERDICT r03 "missing" #2: CFG multiplies rounding noise by up to 6 per guided step and only 5
-    timesteps had been compared.  Two samples in one packed engine batch (per-sample renorm == the reference at B = 1), each
+    timesteps had been compared.  One request (round 6; two until then - the packed-batch case is the 5-timestep test), 
     against its own oracle run: the latent after EVERY Euler step, then the uint8 pixels of the full-size VAE decoder on the
     ENGINE's final latent against the oracle's decoder on the ORACLE's final latent (the end-to-end image, inferencer.py:234-256)."""
     from copy import deepcopy
     from oracle.unimedvl_cpu import KVCache
     from unimedvl_amd.kvcache import NaiveCache
     model, vae, oracle, cfg, ntid = fw
-    B, hw, steps = 2, 256, 50
+    B, hw, steps = 1, 256, 50          # (one request: the oracle's 49 x 3 CPU passes are the test's cost; packed batches: the 5-timestep test above)
     prompts = _prompts([128] * B, 18)
     gen = NaiveCache(cfg.layers)
     gi, kvl, rope = model.prepare_prompts([0] * B, [0] * B, [str(i) for i in range(B)], IdTok(prompts), ntid)
@@ -843,8 +843,11 @@ def test_configs4_mixed_fullwidth(fw):
     torch.cuda.empty_cache()
 
 
-def test_continuous_batcher_fullwidth_against_the_oracle(fw):
-    """serving.ContinuousBatcher checked against the ORACLE directly (not against Bagel.chat on the same HIP path): 7 ragged requests -
+@pytest.mark.parametrize("paged", [False, True])
+def test_continuous_batcher_fullwidth_against_the_oracle(fw, paged):
+    """(paged = True: the same run on the block-table cache, kvcache.PagedCache - 256-token pages from one pool, nothing re-allocated, the
+    pages of a finished request re-used - held to the oracle the same way.)
+    serving.ContinuousBatcher checked against the ORACLE directly (not against Bagel.chat on the same HIP path): 7 ragged requests -
     448 x 448 / 224 x 336 / 224 x 224 images or none, 7..40-token prompts, budgets of 3..8 new tokens - on 3 slots at the 14B widths
     (2 layers), slots reserved for 256 tokens so that the first image request doubles the slabs (twice) while other slots hold
     live contexts, and four requests are admitted into slots freed in flight.  Per request the oracle rebuilds the context
@@ -864,12 +867,16 @@ def test_continuous_batcher_fullwidth_against_the_oracle(fw):
     prompts = _prompts(plens, 811)
     images = [None if sz is None else _synth_image(sz[0], sz[1], 820 + i) for i, sz in enumerate(sizes)]
     ident = lambda x: x   # noqa: E731
-    srv = ContinuousBatcher(model, tok, ntid, ident, slots=3, max_context=16, max_new_tokens=8, check_every=3, use_graph=True)
+    srv = ContinuousBatcher(model, tok, ntid, ident, slots=3, max_context=16, max_new_tokens=8, check_every=3, use_graph=True,
+                            **(dict(paged=True, pool_pages=16, context_limit=2048) if paged else {}))
     cap0 = srv.cache.cap
     rids = [srv.submit([] if im is None else [im], " ".join(str(t) for t in p), max_new_tokens=nb) for im, p, nb in zip(images, prompts, budgets)]
     got = srv.run()
     assert sorted(got) == sorted(rids) and srv.stats["prefills"] == 7
-    assert cap0 == 256 and srv.stats["cache_grows"] >= 2 and srv.cache.cap >= 1024, (cap0, srv.stats, srv.cache.cap)
+    if paged:       # 15 pages serve 7 requests of up to 1026 + 32 + 8 tokens through 3 slots because finished requests return theirs
+        assert srv.stats["cache_grows"] == 0 and srv.cache.pages_in_use() <= 3, (srv.stats, srv.cache.pages_in_use())
+    else:
+        assert cap0 == 256 and srv.stats["cache_grows"] >= 2 and srv.cache.cap >= 1024, (cap0, srv.stats, srv.cache.cap)
     bos, eos = ntid["bos_token_id"], ntid["eos_token_id"]
     sure = flips = 0
     worst_margin = 0.0
@@ -898,5 +905,6 @@ def test_continuous_batcher_fullwidth_against_the_oracle(fw):
                 flips += 1
             fed = t
     print(f"continuous batcher vs oracle: {sure} tokens equal to the oracle's argmax, {flips} inside the 0.25 margin (largest {worst_margin:.3f}); "
-          f"slabs {cap0} -> {srv.cache.cap} tokens per slot in {srv.stats['cache_grows']} doublings")
+          + (f"paged cache, {srv.cache.pool_pages - 1} pages of 256 tokens" if paged else
+             f"slabs {cap0} -> {srv.cache.cap} tokens per slot in {srv.stats['cache_grows']} doublings"))
     assert sure >= 25 and flips <= 3
