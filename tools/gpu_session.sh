@@ -2,7 +2,7 @@
 # ONE parameterised driver for what the round-by-round one-shot scripts (tools/r04_*.sh, r05_*.sh, r06_*.sh: in the git history) did
 # on the GPU box.  Run through gpurun from the build container:
 #     gpurun --timeout 2400 -- 'bash tools/gpu_session.sh <tag> <step> [<step> ...]'
-# Everything a step prints lands in gpurun_out/<tag>/ (merged back by gpurun).  Steps:
+# Everything a step prints lands in gpurun_out/<tag>_session/ (merged back by gpurun).  Steps:
 #   suite                       the round-end GPU suite as the driver runs it (pytest -m gpu -x, 25 slowest tests) + __graft_entry__.smoke()
 #   tests:<pytest args>         e.g. 'tests:tests/test_attn_lazy_gpu.py -k deterministic -s'
 #   bench[:<flags>]             python bench.py <flags> -> <tag>/bench.txt
@@ -14,7 +14,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 TAG=${1:?tag}; shift
-O=gpurun_out/$TAG; mkdir -p $O
+O=gpurun_out/${TAG}_session; mkdir -p $O       # (tools/roofline_profile.sh owns - and removes - gpurun_out/<tag>/)
 DECODE_ONLY="--no-t2i --no-vit --no-vae --no-load-path --no-cpu-baseline --no-fp8 --no-report --no-edit --no-sampled --steps 256"
 line() { python -c "
 import sys, json

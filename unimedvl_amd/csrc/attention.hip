@@ -32,7 +32,7 @@ __device__ __forceinline__ bf16x8 mask_keys(bf16x8 v, int nvalid) {
 // workgroup's range among themselves in runs of 32-key blocks; their (O, m, l) triples meet in LDS (merge in wave order 0 .. wsplit-1,
 // wave w finishing the d-tiles dt = w, w + wsplit, ..) and the workgroup writes ONE partial (or the final rows).  PAGED = the K / V^T
 // operands are page pools addressed through umv_attn_args.page_table (pages of UMV_KV_PAGE = 256 keys; a 32-key block never straddles one).
-template <int HD, int WS>
+template <int HD, int WS, bool PAGED>
 __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_log2e) {
     constexpr int wsplit = WS;
     constexpr int KS = (HD + 31) / 32;   // k-steps over the head dim for S
@@ -89,18 +89,23 @@ __global__ __launch_bounds__(256) void attn_kernel(umv_attn_args a, float scale_
     const int64_t kstride = a.k_key_stride ? a.k_key_stride : HD;     // packed K (k_key_stride > 0): rows cu_q[s] .. of a [T, ...] buffer
     // slab form: one base per (segment, kv head); paged form: the base of the page holding block kb (key / column offsets then count
     // from the page start: kpage0 = first key of that page)
-    const int32_t* ptab = a.page_table ? a.page_table + (int64_t)s * a.page_table_stride : nullptr;
-    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : (ptab ? 0 : s * a.k_seg_stride)) + kh * a.k_head_stride;
-    const bf16_t* vbase = a.vt_slab + (ptab ? 0 : s * a.v_seg_stride) + kh * a.v_head_stride;
+    // (PAGED is a template parameter: the slab kernels carry no trace of it - a run-time test cost the decode step's attention 9.4 vs 8.9 us)
+    const int32_t* ptab = PAGED ? a.page_table + (int64_t)s * a.page_table_stride : nullptr;
+    const bf16_t* kbase = a.k_slab + (a.k_key_stride ? (int64_t)q0 * a.k_key_stride : (PAGED ? 0 : s * a.k_seg_stride)) + kh * a.k_head_stride;
+    const bf16_t* vbase = a.vt_slab + (PAGED ? 0 : s * a.v_seg_stride) + kh * a.v_head_stride;
     auto k_of = [&](int kb, int& kpage0) -> const bf16_t* {
-        if (!ptab) { kpage0 = 0; return kbase; }
-        kpage0 = kb & ~(UMV_KV_PAGE - 1);
-        return kbase + (int64_t)ptab[kb >> UMV_KV_PAGE_LOG2] * a.k_seg_stride;
+        if constexpr (!PAGED) { kpage0 = 0; return kbase; }
+        else {
+            kpage0 = kb & ~(UMV_KV_PAGE - 1);
+            return kbase + (int64_t)ptab[kb >> UMV_KV_PAGE_LOG2] * a.k_seg_stride;
+        }
     };
     auto v_of = [&](int kb, int& kpage0) -> const bf16_t* {
-        if (!ptab) { kpage0 = 0; return vbase; }
-        kpage0 = kb & ~(UMV_KV_PAGE - 1);
-        return vbase + (int64_t)ptab[kb >> UMV_KV_PAGE_LOG2] * a.v_seg_stride;
+        if constexpr (!PAGED) { kpage0 = 0; return vbase; }
+        else {
+            kpage0 = kb & ~(UMV_KV_PAGE - 1);
+            return vbase + (int64_t)ptab[kb >> UMV_KV_PAGE_LOG2] * a.v_seg_stride;
+        }
     };
 
     f32x4 o[DT];
@@ -299,16 +304,21 @@ extern "C" int umv_attn_varlen(const umv_attn_args* ap, umv_stream_t stream) {
     dim3 grid(ws > 1 ? qtiles : (qtiles + wpb - 1) / wpb, a.nkv * a.nsplit, a.nseg), block(64 * wpb);
     if (a.nsplit == 1 && qtiles >= 4 && (a.hd == 128 || a.hd == 72) && umv_attn_prefill_enabled(a.variant) && umv_attn_prefill_can_take(a))
         return umv_attn_prefill_launch(a, qtiles, scale_log2e, s);
-    if (a.hd == 128 && ws == 4)
-        hipLaunchKernelGGL((attn_kernel<128, 4>), grid, block, 4 * 8 * 1024 + 4 * 16 * 2 * 4, s, a, scale_log2e);
-    else if (a.hd == 128 && ws == 2)
-        hipLaunchKernelGGL((attn_kernel<128, 2>), grid, block, 2 * 8 * 1024 + 2 * 16 * 2 * 4, s, a, scale_log2e);
-    else if (a.hd == 128)
-        hipLaunchKernelGGL((attn_kernel<128, 1>), grid, block, 0, s, a, scale_log2e);
+    const bool pg = a.page_table != nullptr;
+    UMV_CHECK(!pg || a.hd == 128, UMV_ERR_UNSUPPORTED, "attn: paged KV is built for head_dim 128 (the LLM's cache); got %d", a.hd);
+#define UMV_ATTN_LAUNCH(HD_, WS_, LDS_)                                                                               \
+    do {                                                                                                               \
+        if (pg) hipLaunchKernelGGL((attn_kernel<HD_, WS_, true>), grid, block, LDS_, s, a, scale_log2e);               \
+        else hipLaunchKernelGGL((attn_kernel<HD_, WS_, false>), grid, block, LDS_, s, a, scale_log2e);                 \
+    } while (0)
+    if (a.hd == 128 && ws == 4) UMV_ATTN_LAUNCH(128, 4, 4 * 8 * 1024 + 4 * 16 * 2 * 4);
+    else if (a.hd == 128 && ws == 2) UMV_ATTN_LAUNCH(128, 2, 2 * 8 * 1024 + 2 * 16 * 2 * 4);
+    else if (a.hd == 128) UMV_ATTN_LAUNCH(128, 1, 0);
+#undef UMV_ATTN_LAUNCH
     else if (a.hd == 72)
-        hipLaunchKernelGGL((attn_kernel<72, 1>), grid, block, 0, s, a, scale_log2e);
+        hipLaunchKernelGGL((attn_kernel<72, 1, false>), grid, block, 0, s, a, scale_log2e);
     else if (a.hd == 512 && a.nsplit == 1)   // VAE mid-block attention, single head of 512 (autoencoder.py:50-62)
-        hipLaunchKernelGGL((attn_kernel<512, 1>), grid, block, 0, s, a, scale_log2e);
+        hipLaunchKernelGGL((attn_kernel<512, 1, false>), grid, block, 0, s, a, scale_log2e);
     else
         UMV_CHECK(false, UMV_ERR_UNSUPPORTED, "attn: head_dim %d unsupported (128, 72, 512)", a.hd);
     UMV_LAUNCH_CHECK();

@@ -265,9 +265,17 @@ class PagedCache:
         if nseg != len(self.lens):
             raise ValueError(f"cache holds {len(self.lens)} samples, call has {nseg}")
         changed = []
+        want = 0                              # all-or-nothing: check the reach and the pool before taking a single page
         for s, n in enumerate(need):
             if n > self.cap:
                 raise ValueError(f"segment {s}: {n} tokens exceed the page table's reach of {self.cap} (max_context)")
+            pages = self._pages(s)
+            want += max(0, (n + ops.KV_PAGE - 1) // ops.KV_PAGE - len(pages))
+            want += int(n > self.lens[s] and bool(pages) and self.lens[s] % ops.KV_PAGE != 0 and self.pool.refs[pages[-1]] > 1)
+        if want > len(self.pool.free):
+            raise RuntimeError(f"paged KV pool exhausted: {want} pages wanted, {len(self.pool.free)} of {self.pool.npages - 1} free "
+                               f"({ops.KV_PAGE} tokens each): raise pool_pages")
+        for s, n in enumerate(need):
             pages = self._pages(s)
             # copy-on-write: the last, partially filled page is shared with a snapshot and this call appends to it
             if n > self.lens[s] and pages and self.lens[s] % ops.KV_PAGE and self.pool.refs[pages[-1]] > 1:
