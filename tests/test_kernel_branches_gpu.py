@@ -665,3 +665,33 @@ def test_attn_lazy_softmax():
         assert out.returncode == 0, out.stderr[-2000:]
         runs = [ln for ln in out.stdout.splitlines() if ln.startswith("run ")]
         assert len(runs) == 5 and all("tokens differing 0:" in ln for ln in runs), out.stdout
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8208, 37888, 3584, "swiglu"), (8208, 3584, 18944, "residual"), (8192, 4304, 1152, "gelu"), (8192, 1152, 4304, "residual"),
+                                      (2064, 4608, 3584, "bias"), (272, 4608, 3584, "bias"), (8, 37888, 3584, "swiglu"), (32, 3584, 18944, "residual")])
+def test_gemm_race_screen(ops, M, N, K, epi):
+    """Multi-run race screen of the hand-synchronised GEMM kernels at the shapes the bench legs run (counted vmcnt waits, LDS-DMA rings, one
+    barrier per k-step: an early read "passes whenever the DMA happens to land first", guide section on LDS-DMA ordering; round 6 found a
+    nondeterministic attention variant that every small-shape parity case had passed).  The same launch 25 times with all CUs busy: every
+    output must equal the first bit for bit."""
+    x = rnd((M, K), 11)
+    if epi == "swiglu":
+        I = N // 2
+        lin = ops.PackedLinear.from_gate_up(rnd((I, K), 12, 1 / math.sqrt(K)), rnd((I, K), 13, 1 / math.sqrt(K)))
+        kw, n_out = {}, I
+    else:
+        lin = ops.PackedLinear.from_weight(rnd((N, K), 12, 1 / math.sqrt(K)), rnd((N,), 14))
+        kw, n_out = {}, N
+        if epi == "residual":
+            kw["residual"] = rnd((M, N), 15)
+        elif epi == "gelu":
+            kw["act"] = "gelu_tanh"
+    first, bad = None, 0
+    for _ in range(25):
+        out = torch.zeros((M, n_out), dtype=BF16, device="cuda")
+        ops.gemm(x, lin, out=out, **kw)
+        if first is None:
+            first = out
+        else:
+            bad += int(not torch.equal(out, first))
+    assert torch.isfinite(first.float()).all() and bad == 0, f"{bad} of 24 repeats differ from the first launch"
