@@ -4,7 +4,8 @@ the bench shape with peaked scores, reports which elements differ from the per-t
 parity, lane row - and, in a UMV_ATTN_PAIR_DEBUG=1 build, the same for the bisecting forms (variant bits 8..10):
   1 = s_nop guard on the QK^T accumulators before the softmax   2 = ds_bpermute instead of v_permlane*_swap
   3 = 16 wait states between the swaps and their consumers        4 = rare path unconditional (no branch)
-  5 = 32 wait states between the QK^T MFMAs of a K fragment and the next fragment's ds_read"""
+  5 = 32 wait states between the QK^T MFMAs of a K fragment and the next fragment's ds_read
+  6 = one v_cmp for both tiles' triggers (no v_cmp_e64 -> s_or_b64 -> s_cbranch_vccz chain)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -56,7 +57,7 @@ if os.environ.get("STATE"):
 ref = run(F | L.ATTN_TQ2)
 assert torch.equal(ref, run(F | L.ATTN_TQ2)) and torch.equal(ref, run(F | L.ATTN_TQ1))
 G = nq // nkv
-for dbg in range(0, 6 if os.environ.get("UMV_ATTN_PAIR_DEBUG") else 1):
+for dbg in range(0, 7 if os.environ.get("UMV_ATTN_PAIR_DEBUG") else 1):
     v = F | L.ATTN_TQ2 | L.ATTN_PAIR | (dbg << 8)
     nbad, shown = 0, 0
     for rep in range(int(os.environ.get("REPS", "20"))):

@@ -95,6 +95,9 @@ __device__ __forceinline__ bool attn_softmax_lazy(const f32x4 (&st)[TQ][2], int 
         emax[u] = fmaxf(fmaxf(ea, eb), fmaxf(e[u][3][0], e[u][3][1]));
         trig = trig || emax[u] > thr_run[u];
     }
+    if constexpr (DBG == 6 && TQ == 2) {      // bisect: ONE compare for both tiles (thr = -inf while unset: emax - thr = +inf, or NaN for an all-masked row)
+        trig = fmaxf(emax[0] - thr_run[0], emax[1] - thr_run[1]) > 0.f;
+    }
     const bool moved = DBG == 4 ? true : __any(trig);
     if (moved) {
         // the rows' cross-lane maxima first, then the selects, branch-free
@@ -590,6 +593,7 @@ int umv_attn_prefill_launch(const umv_attn_args& a, int /*qtiles of the per-wave
                 case 3: return launch_prefill<128, 2, 5>(a, qtiles, scale_log2e, dense, s);
                 case 4: return launch_prefill<128, 2, 6>(a, qtiles, scale_log2e, dense, s);
                 case 5: return launch_prefill<128, 2, 7>(a, qtiles, scale_log2e, dense, s);
+                case 6: return launch_prefill<128, 2, 8>(a, qtiles, scale_log2e, dense, s);
                 default: return launch_prefill<128, 2, 2>(a, qtiles, scale_log2e, dense, s);
             }
 #else
