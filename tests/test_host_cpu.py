@@ -353,13 +353,3 @@ def test_attention_prefill_isa_has_no_scratch(tmp_path):
             # the lazy softmax is compiler-visible throughout: no inline asm next to its v_permlane*_swap steps (round 6)
             body = s[s.index(n + ":"):b]
             assert not re.search(r";;#ASMSTART\s+v_", body), f"{n}: inline-asm VALU instruction in a lazy kernel"
-            # round 6 (profiles/r06_attn_pair_nondeterminism.txt): the nondeterministic paired-call kernels copy 64-bit register pairs with
-            # v_mov_b64 at a branch merge inside the key loop; every kernel that passes the determinism stress has none there.  Cause not
-            # proven - until it is, a build that brings the instruction into a shipped kernel's loop must not go unnoticed
-            in_loop, hits = False, 0              # (the compiler marks a loop's blocks: "; =>This Inner Loop Header" / ";   in Loop: Header=...")
-            for ln in body.splitlines():
-                if ln.startswith(".LBB") or ln.startswith("; %bb."):
-                    in_loop = "Loop" in ln
-                elif in_loop and "v_mov_b64" in ln:
-                    hits += 1
-            assert hits == 0, f"{n}: {hits} v_mov_b64 inside the key loop - re-run the determinism stress before shipping this build"

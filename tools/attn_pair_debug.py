@@ -9,7 +9,10 @@ parity, lane row - and, in a UMV_ATTN_PAIR_DEBUG=1 build, the same for the bisec
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from unimedvl_amd import ops, _lib as L
+from unimedvl_amd import _lib as L
+if os.environ.get("UMV_LIB_PATH"):        # another build of the library (e.g. the v_mov_b64-free object of profiles/r06_attn_pair_nondeterminism.txt)
+    L.LIB_PATH = os.environ["UMV_LIB_PATH"]
+from unimedvl_amd import ops
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_attn_lazy_gpu import make_case, fill_slab, HEADS
 
