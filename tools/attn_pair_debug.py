@@ -27,8 +27,15 @@ F = L.ATTN_FORCE
 
 
 NWG = ((Lq * (nq // nkv) + 15) // 16 + 7) // 8 * nkv * B
+POISON = int(os.environ.get("POISON", "0"))        # 1 = LDS, 2 = VGPRs, 3 = both: tools/poison.hip in front of every call
+if POISON:
+    import ctypes
+    _pz = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libpoison.so"))
+    _sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 def run(variant, state=None):
     out = torch.zeros_like(q)
+    if POISON:
+        _pz.poison(POISON, 0x7FC07FC0, ctypes.c_void_p(_sink.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     ops.attention(q, out, slab, cu, kvl, nq, nkv, hd, False, Lq, Lq, variant=variant, workspace=state)
     torch.cuda.synchronize()
     return out
@@ -68,6 +75,8 @@ for dbg in range(0, 7 if os.environ.get("UMV_ATTN_PAIR_DEBUG") else 1):
         bad = (out != ref)
         if bad.any():
             nbad += 1
+            if shown < 4 and POISON:
+                print(f"  dbg {dbg} rep {rep}: non-finite outputs: {int((~torch.isfinite(out.float())).sum())}")
             rows = bad.any(-1).nonzero()                      # (token, head)
             if shown < 4:
                 shown += 1
