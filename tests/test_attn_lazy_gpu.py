@@ -233,26 +233,30 @@ def test_lazy_kernels_at_bench_shapes(ops):
 
 
 def test_lazy_kernels_are_deterministic(ops):
-    """Stress: 40 calls per variant on the bench shapes with peaked scores (the rare path fires in every wave); every output equals the
-    first.  (A paired-call form of the softmax - both q-tiles of a wave in one call - fails exactly this test, 39 of 39 repeats, while it
-    passes every small-shape parity case: profiles/r06_attn_pair_nondeterminism.txt.  It is not in the product build.)"""
+    """Stress: 60 calls per variant on the shapes the bench legs run - image spans, the ViT at 8 and 32 images, a 4 096-token causal
+    prefill, the guided flow pass - with peaked scores (the rare path fires in every wave), every CU busy and several waves per SIMD; every
+    output equals the first.  (A paired-call form of the softmax - both q-tiles of a wave in one call - fails exactly this test, 39 of 39
+    repeats, while it passes every small-shape parity case, and the SAME code passes at one wave per SIMD:
+    profiles/r06_attn_pair_nondeterminism.txt.  It is not in the product build; the exact-maximum kernels are screened here too.)"""
     L_, V = _variants()
-    for hd, L in ((128, 1026), (72, 1024)):
+    cases = [(128, [1026] * 8, [1026] * 8, False), (72, [1024] * 8, [1024] * 8, False), (72, [1024] * 32, [1024] * 32, False),
+             (128, [4096], [4096], True), (128, [258] * 12, [388] * 12, False), (128, [700, 513, 640, 1000], [1726, 553, 640, 1007], True)]
+    for hd, q_lens, k_lens, causal in cases:
         nq, nkv, _ = HEADS[hd]
-        q, ks, vs = make_case("scale8", nq, nkv, hd, [L] * 8, [L] * 8, seed=5)
+        q, ks, vs = make_case("scale8", nq, nkv, hd, q_lens, k_lens, seed=5)
         slab = fill_slab(ops, ks, vs, nkv, hd)
-        cu = torch.arange(0, 9 * L, L, dtype=torch.int32).cuda()
-        kvl = torch.full((8,), L, dtype=torch.int32).cuda()
-        for name in ["tq2", "tq1"]:
+        cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32).cuda()
+        kvl = torch.tensor(k_lens, dtype=torch.int32).cuda()
+        for name in ["tq2", "tq1", "exact_tq2"]:
             first, bad = None, 0
-            for _ in range(40):
+            for _ in range(60):
                 out = torch.zeros_like(q)
-                ops.attention(q, out, slab, cu, kvl, nq, nkv, hd, False, L, L, variant=V[name])
+                ops.attention(q, out, slab, cu, kvl, nq, nkv, hd, causal, max(q_lens), max(k_lens), variant=V[name])
                 if first is None:
                     first = out
                 else:
                     bad += int(not torch.equal(out, first))
-            assert bad == 0, f"hd {hd} {name}: {bad} of 39 repeats differ from the first call"
+            assert bad == 0, f"hd {hd} x {len(q_lens)} segments of {q_lens[0]} {name}: {bad} of 59 repeats differ from the first call"
 
 
 @pytest.mark.parametrize("dist", ["scale32", "ramp", "outlier_last", "outlier_first", "mixed"])
