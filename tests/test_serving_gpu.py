@@ -198,8 +198,10 @@ def test_chat_with_pooled_cache_equals_plain_chat(model):
     assert got == want
 
 
-def test_mixed_vqa_and_t2i_requests_interleaved(tiny_weights):
-    """serving.MixedBatcher (BASELINE.json configs[4]: mixed VQA + T2I interleaved batch): VQA decode slots and a
+@pytest.mark.parametrize("paged", [False, True])
+def test_mixed_vqa_and_t2i_requests_interleaved(tiny_weights, paged):
+    """(paged: the VQA slots on the block-table cache, kvcache.PagedCache.)
+    serving.MixedBatcher (BASELINE.json configs[4]: mixed VQA + T2I interleaved batch): VQA decode slots and a
     text-to-image group advance in the same step stream.  Every answer equals Bagel.chat's for that request alone and every
     image's final latent equals Bagel.generate_image's for that prompt and starting noise alone, bit for bit."""
     from oracle.toy_tokenizer import ToyTokenizer
@@ -240,7 +242,7 @@ def test_mixed_vqa_and_t2i_requests_interleaved(tiny_weights):
     want_lat = [alone(p, n) for p, n in t2i]
 
     srv = MixedBatcher(model, vae, tok, NEW_TOKEN_IDS, ident, slots=3, t2i_batch=2, flow_steps_per_round=2, max_context=256,
-                       max_new_tokens=8, check_every=3)
+                       max_new_tokens=8, check_every=3, paged=paged)
     rids = [srv.submit(images, prompt, max_new_tokens=nb) for (images, prompt), nb in zip(reqs, budgets)]
     iids = [srv.submit_t2i(p, hw, init_noise=n, **kw) for p, n in t2i]
     got = srv.run()
